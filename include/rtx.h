@@ -1,0 +1,170 @@
+/*
+ * rtx.h -- C ABI of the MI355X-native trace backend for ellishg/rust-raytracer.
+ *
+ * The reference has no FFI of its own: its hot path sits behind the free function
+ * `world::render(camera, objects, lights, background_color, samples_per_pixel,
+ * max_ray_bounces, path, num_threads)` (src/world.rs:17-29).  These entry points are
+ * what a thin `rtx-sys` crate binds so that `render` keeps its signature and replaces
+ * the thread-pool region src/world.rs:38-74 with one call.
+ *
+ * Conventions: every function returns RTX_OK (0) or a negative rtx_status and never
+ * throws or aborts across the boundary; rtx_last_error() gives the text.  Input
+ * pointers are borrowed for the duration of the call; output buffers are owned by the
+ * caller.  One rtx_ctx per GPU, called from one host thread at a time.  The library
+ * has no CPU fallback: without a usable HIP device rtx_init fails.
+ */
+#ifndef RTX_H
+#define RTX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = -1,    /* bad argument / malformed scene */
+    RTX_ERR_HIP = -2,        /* a HIP runtime call failed */
+    RTX_ERR_NO_SCENE = -3,   /* render before rtx_upload_scene */
+    RTX_ERR_CAPACITY = -4,   /* scene exceeds a documented device limit */
+    RTX_ERR_DEGENERATE = -5, /* BVH build cannot terminate (reference recurses forever, bvh.rs:221-230) */
+    RTX_ERR_IO = -6
+} rtx_status;
+
+/* Object / material / light vocabularies of the reference. */
+enum { RTX_OBJ_SPHERE = 0, RTX_OBJ_TRIANGLE = 1, RTX_OBJ_QUAD = 2 };           /* object.rs:14-18 */
+enum { RTX_MAT_NONE = 0, RTX_MAT_PHONG = 1, RTX_MAT_REFLECTIVE = 2,
+       RTX_MAT_REFRACTIVE = 3, RTX_MAT_COMPOSITION = 4 };                      /* material.rs:21-31 */
+enum { RTX_TEX_NONE = 0, RTX_TEX_FLAT = 1, RTX_TEX_IMAGE = 2 };                /* material.rs:14-18 */
+enum { RTX_LIGHT_AMBIENT = 0, RTX_LIGHT_POINT = 1, RTX_LIGHT_DIRECTIONAL = 2,
+       RTX_LIGHT_CONE = 3 };                                                   /* light.rs:12-17 */
+
+/* Flat restatement of what `render` receives: Vec<Object> (object.rs:20-26), the
+ * Material trees (material.rs:33-37), Vec<Light> (light.rs:19-22), background
+ * (main.rs:111) and the Camera (camera.rs:5-9).  All matrices column-major f32. */
+typedef struct rtx_scene_desc {
+    uint32_t n_objects;
+    const int32_t *obj_type;
+    const float *obj_verts;       /* n*12: sphere = centre xyz + radius; tri = a,b,c; quad = a,b,c,d */
+    const int32_t *obj_xform;     /* n: index into xforms */
+    const int32_t *obj_material;  /* n: index into materials */
+    uint32_t n_xforms;
+    const float *xforms;          /* n_xforms*32: object_to_world (16) then world_to_object (16) */
+    uint32_t n_materials;
+    const int32_t *mat_root;      /* root node of the material tree */
+    const int32_t *mat_tex_kind;
+    const float *mat_tex_color;   /* n*3 (Flat) */
+    const int32_t *mat_tex_id;    /* (Image) */
+    uint32_t n_mat_nodes;
+    const int32_t *node_type;
+    const float *node_params;     /* n*3: Phong diffuse,specular,shininess | Refractive index */
+    const int32_t *node_child_first;
+    const int32_t *node_child_count;
+    uint32_t n_mat_children;
+    const int32_t *child_node;    /* Composition entries: (material node, coefficient) */
+    const float *child_coef;
+    uint32_t n_textures;
+    const int32_t *tex_w;
+    const int32_t *tex_h;
+    const uint64_t *tex_offset;   /* byte offset of each RGB8 image in tex_data */
+    const uint8_t *tex_data;
+    uint32_t n_lights;
+    const int32_t *light_type;
+    const float *light_pos;       /* n*3 */
+    const float *light_dir;       /* n*3, normalised as Light::new_* does (light.rs:42,54) */
+    const float *light_angle_deg; /* n */
+    const float *light_color;     /* n*3 */
+    float background[3];
+    float camera_to_world[16];    /* camera.rs:20 */
+    uint32_t width, height;
+} rtx_scene_desc;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Counters of one render call.  One ray = one Bvh::get_closest_intersection query of the
+ * reference (world.rs:118, light.rs:90,111). */
+typedef struct rtx_stats {
+    uint64_t primary_rays, bounce_rays, shadow_rays;
+    uint64_t nodes_visited;     /* internal BVH nodes fetched (64 B each); 0 unless counting is on */
+    uint64_t prims_tested;      /* primitive records fetched (64 B each); 0 unless counting is on */
+    double trace_ms;            /* host wall time raygen..resolve (stream-synchronised) */
+    double closest_kernel_ms;   /* HIP-event time summed over trace_closest launches */
+    double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches */
+    uint32_t closest_launches, shadow_launches;
+    uint32_t batches;
+    uint32_t reserved;
+} rtx_stats;
+
+/* BVH facts after upload (bvh.rs:18-24 logs the same numbers). */
+typedef struct rtx_bvh_info {
+    uint32_t n_objects, n_internal, n_leaves, depth;
+    float total_sa;
+    double build_seconds, flatten_seconds, upload_seconds;
+    uint64_t device_bytes;
+} rtx_bvh_info;
+
+/* Image-tile partition (one process per GPU): the image is cut into tile x tile pixel
+ * squares numbered row-major; this context renders tiles with index % nranks == rank.
+ * Replaces the column-per-job thread pool of world.rs:38-68. */
+typedef struct rtx_partition {
+    uint32_t tile;    /* tile edge in pixels, multiple of 8 (default 32) */
+    uint32_t rank;
+    uint32_t nranks;
+} rtx_partition;
+
+enum { RTX_FLAG_COUNT_VISITS = 1u,   /* fill rtx_stats.nodes_visited / prims_tested (slower) */
+       RTX_FLAG_REFERENCE_TRAVERSAL = 2u /* visit both children, no pruning (bvh.rs:359-395 verbatim) */ };
+
+/* Create a context on HIP device `device`.  Replaces ThreadPool::new (world.rs:38). */
+int rtx_init(int device, rtx_ctx **out);
+void rtx_destroy(rtx_ctx *ctx);
+const char *rtx_last_error(rtx_ctx *ctx); /* ctx may be NULL: last rtx_init error */
+
+/* Replaces World::new -> Bvh::new (world.rs:98-111, bvh.rs:13-26, 334-357): builds the
+ * reference's SAH tree topology on the host, flattens it into 64-byte node / primitive
+ * records and uploads everything to HBM once. */
+int rtx_upload_scene(rtx_ctx *ctx, const rtx_scene_desc *desc);
+int rtx_bvh_info_get(rtx_ctx *ctx, rtx_bvh_info *out);
+/* Leaf-order permutation of object indices and preorder node sizes of the built tree
+ * (parity check of the topology against the reference builder). Returns node count. */
+int rtx_bvh_digest(rtx_ctx *ctx, uint32_t *leaf_order, uint32_t *preorder_sizes);
+
+/* Replaces the pool + gather of world.rs:38-74 plus the quantisation of world.rs:76-80:
+ * traces every (pixel, sample) of this rank's tiles and resolves them to RGB8.
+ * out_rgb8: host buffer W*H*3 (row-major, pixel (0,0) top-left); only this rank's pixels
+ * are written.  out_rgb_f32 (optional) receives the averaged, clamped colour (W*H*3).
+ * spp == 1 uses no jitter (world.rs:47-51); spp > 1 uses the counter-based jitter(seed). */
+int rtx_render(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
+               const rtx_partition *part_or_null, uint32_t flags,
+               uint8_t *out_rgb8, float *out_rgb_f32_or_null, rtx_stats *stats_or_null);
+
+/* Same, but the result stays in HBM: d_tiles_rgb8 is a DEVICE buffer of
+ * rtx_partition_pixels()*3 bytes receiving this rank's tiles packed
+ * [local tile][row in tile][col in tile][rgb] (pixels outside the image are zero).
+ * The launch is asynchronous on rtx_stream(); used for the multi-GPU RCCL gather. */
+int rtx_render_device(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
+                      const rtx_partition *part_or_null, uint32_t flags,
+                      void *d_tiles_rgb8, rtx_stats *stats_or_null);
+/* Number of pixel slots (tiles * tile * tile) this rank owns under `part`. */
+uint64_t rtx_partition_pixels(rtx_ctx *ctx, const rtx_partition *part_or_null);
+void *rtx_stream(rtx_ctx *ctx); /* hipStream_t the kernels are launched on */
+int rtx_synchronize(rtx_ctx *ctx);
+
+/* Hit-ID parity: closest hit of the primary ray of sample `sample` of every pixel
+ * (camera.rs:32-47 + bvh.rs:33-35).  out_obj: object index in rtx_scene_desc order,
+ * 0xFFFFFFFF = miss; out_t: world-space t.  Both W*H, row-major. */
+int rtx_trace_primary(rtx_ctx *ctx, uint32_t sample, int use_jitter, uint64_t seed,
+                      uint32_t flags, uint32_t *out_obj, float *out_t);
+/* Closest hit of n caller-supplied rays (origin xyz, direction xyz; the direction is
+ * normalised as Ray::new does, ray.rs:11-16).  Bvh::get_closest_intersection, bvh.rs:33-35. */
+int rtx_trace_rays(rtx_ctx *ctx, const float *org_dir, uint64_t n, uint32_t flags,
+                   uint32_t *out_obj, float *out_t);
+/* World::trace_ray(ray, depth) for n caller-supplied rays (world.rs:115-131): rgb f32. */
+int rtx_shade_rays(rtx_ctx *ctx, const float *org_dir, uint64_t n, uint32_t depth,
+                   float *out_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+/*
+ * rtx_host.h -- host-side callers of the trace path, exported as C so that tests, the
+ * bench and the CLI share one implementation.  These stand in for the parts of the
+ * reference that sit either side of the hot path and stay on the host:
+ *   scene construction   src/scene.rs:11-226  (load_basic, load_random_spheres, load_suzanne,
+ *                                              default_camera) + the synthetic bench scenes
+ *   mesh / texture input src/object.rs:30-91 (OBJ), src/material.rs:40-47 (PNG decode)
+ *   image output         src/world.rs:76-81 (PNG encode)
+ * (The C++ mirror of the reference's own API -- Object::new_sphere, Light::new_cone,
+ * render(...) -- is rust-raytracer_amd/csrc/host_scene.h.)
+ */
+#ifndef RTX_HOST_H
+#define RTX_HOST_H
+#include "rtx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtx_host_scene rtx_host_scene;
+
+/* Built-in scenes by name.  `width` = -w/--pixel_width (square viewport, scene.rs:218-226).
+ * media_dir holds Suzanne.obj and texture.png (the reference's media/).  Names:
+ *   "basic"            load_basic()                                    scene.rs:11-108
+ *   "random_spheres"   load_random_spheres(param or 1000)              scene.rs:111-186
+ *   "suzanne"          load_suzanne()                                  scene.rs:188-214
+ *   "basic_suzanne"    BASELINE config 2: load_basic + load_suzanne + directional light
+ *   "scan"             BASELINE config 3: load_basic + 4 synthetic scan-like meshes,
+ *                      param = total triangles (0 = 2,374,525)
+ *   "scan_glass"       BASELINE config 4: same geometry, mirror+glass+Phong compositions
+ *   "soup"             BASELINE config 5: param random triangles (0 = 20,000,000), 4 point lights
+ * Returns NULL on error (rtx_host_last_error()). */
+rtx_host_scene *rtx_scene_builtin(const char *name, uint32_t width, const char *media_dir, uint64_t param);
+const rtx_scene_desc *rtx_scene_get_desc(const rtx_host_scene *s);
+void rtx_scene_free(rtx_host_scene *s);
+const char *rtx_host_last_error(void);
+
+/* PNG (8-bit, non-interlaced) over zlib.  read: *out_rgb is malloc'ed RGB8 (alpha dropped
+ * as image::DynamicImage::to_rgb does, material.rs:45); free with rtx_host_free. */
+int rtx_png_read_rgb8(const char *path, uint32_t *w, uint32_t *h, uint8_t **out_rgb);
+int rtx_png_write_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *rgb);
+void rtx_host_free(void *p);
+
+/* world::render (world.rs:17-29) on a built-in scene: upload, trace on `device`, save PNG.
+ * num_threads is accepted for signature compatibility and used only for the BVH build. */
+int rtx_render_builtin_to_png(const char *scene, uint32_t width, const char *media_dir, uint64_t param,
+                              uint32_t samples_per_pixel, uint32_t max_ray_bounces, const char *path,
+                              uint32_t num_threads, int device);
+
+/* Host half of rtx_upload_scene without a GPU: builds the reference-topology BVH
+ * (bvh.rs:334-357) and flattens it; reports the leaf-order permutation (n_objects entries),
+ * the preorder node sizes (up to 2*n_objects entries), depth and total surface area
+ * (bvh.rs:404-409,419-426).  Returns the node count or a negative rtx_status. */
+int rtx_host_bvh_digest(const rtx_scene_desc *desc, int threads, uint32_t *leaf_order, uint32_t *preorder_sizes,
+                        uint32_t *depth, float *total_sa, uint32_t *n_internal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,88 @@
+// Data layout shared by the host flattener and the HIP kernels.
+//
+// Everything the kernels chase per ray is a 64-byte, 64-byte-aligned record so that one
+// node or primitive visit is exactly one cache line (four dwordx4 loads per lane).
+#pragma once
+#include <stdint.h>
+
+namespace rtx {
+
+// One internal BVH node (BvhTree::Node, bvh.rs:323-326).  The boxes of BOTH children are
+// stored in the parent, so a visit decides both descents from one line; the reference
+// tests a node's own box on entry (bvh.rs:362,377), which is the same predicate evaluated
+// one level later.  Child reference: bit 31 clear = internal node index; bit 31 set =
+// leaf, bits 30..3 = first primitive (leaf order), bits 2..0 = primitive count (<= 4).
+struct alignas(64) BvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t left, right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "node must be one cache line");
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+constexpr uint32_t INVALID_PRIM = 0xFFFFFFFEu;  // sample slot outside the image
+
+// One primitive in leaf order (Object, object.rs:20-26, minus the per-object matrices,
+// which live in the Xform table).  v[0..11]: sphere = centre, radius, radius^2;
+// triangle = a,b,c; quad = a,b,c,d.  n = normalize((b-a)x(c|d - a)) precomputed with the
+// reference's arithmetic (object.rs:168,191).  meta: bits 1..0 type, 15..2 xform id,
+// 31..16 material id.
+struct alignas(64) Prim {
+    float v[12];
+    float n[3];
+    uint32_t meta;
+};
+static_assert(sizeof(Prim) == 64, "primitive must be one cache line");
+
+struct Xform {
+    float o2w[16];
+    float w2o[16];
+};
+
+// Flattened material: a post-order program evaluated by the resolve kernel with a small
+// accumulator stack (material.rs:118-206).
+enum MatOp : uint32_t {
+    OP_NONE = 0,        // val = gray 0.5                       (material.rs:204)
+    OP_PHONG = 1,       // val = Phong(kd,ks,shininess)         (material.rs:144-184)
+    OP_REFLECT = 2,     // val = colour of bounce child #arg    (material.rs:185-193)
+    OP_REFRACT = 3,     // val = colour of bounce child #arg    (material.rs:194-203)
+    OP_BEGIN = 4,       // push acc = (0,0,0)                   (material.rs:143)
+    OP_ITEM = 5,        // acc = acc + coef * val               (material.rs:132-143)
+    OP_END = 6          // val = pop acc
+};
+struct MatInstr {
+    uint32_t op;
+    uint32_t arg;       // bounce child slot for REFLECT/REFRACT
+    float p0, p1, p2;   // Phong kd,ks,shininess | refraction index | ITEM coefficient
+    uint32_t pad[3];
+};
+struct MaterialRec {
+    uint32_t prog_first, prog_count;
+    uint32_t n_bounce;          // bounce leaves (children spawned per hit)
+    uint32_t tex_kind, tex_id;
+    float tex_color[3];
+};
+struct TextureRec {
+    uint32_t w, h;
+    uint64_t offset;
+};
+struct LightRec {
+    uint32_t type;
+    float pos[3];
+    float dir[3];
+    float angle_deg;
+    float color[3];
+    uint32_t pad;
+};
+
+enum : uint32_t { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTIONAL = 2, LIGHT_CONE = 3 };  // light.rs:12-17
+
+constexpr int MAX_LIGHTS = 16;
+constexpr int MAX_BOUNCE_LEAVES = 4;   // bounce leaves per material
+constexpr int MAX_COMP_DEPTH = 4;      // nesting of Composition
+constexpr int LDS_STACK = 24;          // per-lane traversal stack entries kept in LDS
+constexpr int MAX_TREE_DEPTH = 120;    // LDS_STACK + global spill entries per lane
+
+}  // namespace rtx

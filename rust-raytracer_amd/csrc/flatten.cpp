@@ -1,0 +1,241 @@
+#include "flatten.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace rtx {
+
+namespace {
+
+struct Emit {
+    const BuiltBvh &bvh;
+    FlatScene &out;
+
+    static float sa(const BuildNode &n) {  // AABB::surface_area (bvh.rs:147-150)
+        float dx = n.mx[0] - n.mn[0], dy = n.mx[1] - n.mn[1], dz = n.mx[2] - n.mn[2];
+        return 2.0f * dx * dy + 2.0f * dx * dz + 2.0f * dz * dy;
+    }
+
+    // Returns the child reference of build node `bn`; accumulates total_sa in the
+    // reference's order: sa(node) + total(left) + total(right).
+    uint32_t emit(int32_t bn, float &total) {
+        const BuildNode &n = bvh.nodes[bn];
+        out.preorder_sizes.push_back(n.count);
+        if (n.left < 0) {
+            out.n_leaves++;
+            total = sa(n);
+            return LEAF_BIT | (n.first << 3) | n.count;
+        }
+        uint32_t idx = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        float tl, tr;
+        uint32_t l = emit(n.left, tl);
+        uint32_t r = emit(n.right, tr);
+        const BuildNode &L = bvh.nodes[n.left], &R = bvh.nodes[n.right];
+        BvhNode &o = out.nodes[idx];
+        for (int k = 0; k < 3; k++) {
+            o.lmin[k] = L.mn[k];
+            o.lmax[k] = L.mx[k];
+            o.rmin[k] = R.mn[k];
+            o.rmax[k] = R.mx[k];
+        }
+        o.left = l;
+        o.right = r;
+        o.pad[0] = o.pad[1] = 0;
+        total = sa(n) + tl + tr;
+        return idx;
+    }
+};
+
+// Material tree -> post-order program (material.rs:118-206).
+int emit_material(const rtx_scene_desc &d, int node, int depth, std::vector<MatInstr> &prog, uint32_t &n_bounce,
+                  std::string &err) {
+    if (node < 0 || (uint32_t)node >= d.n_mat_nodes) {
+        err = "material node index out of range";
+        return RTX_ERR_INVALID;
+    }
+    MatInstr ins;
+    std::memset(&ins, 0, sizeof(ins));
+    int type = d.node_type[node];
+    const float *p = d.node_params + (size_t)node * 3;
+    switch (type) {
+        case RTX_MAT_NONE:
+            ins.op = OP_NONE;
+            prog.push_back(ins);
+            return RTX_OK;
+        case RTX_MAT_PHONG:
+            ins.op = OP_PHONG;
+            ins.p0 = p[0];
+            ins.p1 = p[1];
+            ins.p2 = p[2];
+            prog.push_back(ins);
+            return RTX_OK;
+        case RTX_MAT_REFLECTIVE:
+        case RTX_MAT_REFRACTIVE:
+            ins.op = type == RTX_MAT_REFLECTIVE ? OP_REFLECT : OP_REFRACT;
+            ins.arg = n_bounce++;
+            ins.p0 = p[0];
+            prog.push_back(ins);
+            return RTX_OK;
+        case RTX_MAT_COMPOSITION: {
+            if (depth >= MAX_COMP_DEPTH) {
+                err = "Composition nested deeper than 4";
+                return RTX_ERR_CAPACITY;
+            }
+            ins.op = OP_BEGIN;
+            prog.push_back(ins);
+            int first = d.node_child_first[node], cnt = d.node_child_count[node];
+            if (first < 0 || cnt < 0 || (uint32_t)(first + cnt) > d.n_mat_children) {
+                err = "material child range out of bounds";
+                return RTX_ERR_INVALID;
+            }
+            for (int k = 0; k < cnt; k++) {
+                int rc = emit_material(d, d.child_node[first + k], depth + 1, prog, n_bounce, err);
+                if (rc != RTX_OK) return rc;
+                MatInstr it;
+                std::memset(&it, 0, sizeof(it));
+                it.op = OP_ITEM;
+                it.p0 = d.child_coef[first + k];
+                prog.push_back(it);
+            }
+            MatInstr en;
+            std::memset(&en, 0, sizeof(en));
+            en.op = OP_END;
+            prog.push_back(en);
+            return RTX_OK;
+        }
+        default: err = "unknown material node type"; return RTX_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err) {
+    out = FlatScene();
+    if (d.n_xforms == 0 || d.n_xforms > 16384) {
+        err = "scene needs between 1 and 16384 transforms";
+        return d.n_xforms == 0 ? RTX_ERR_INVALID : RTX_ERR_CAPACITY;
+    }
+    if (d.n_materials == 0 || d.n_materials > 65536) {
+        err = "scene needs between 1 and 65536 materials";
+        return d.n_materials == 0 ? RTX_ERR_INVALID : RTX_ERR_CAPACITY;
+    }
+    if (d.n_lights > (uint32_t)MAX_LIGHTS) {
+        err = "more than 16 lights";
+        return RTX_ERR_CAPACITY;
+    }
+    if (d.n_objects >= (1u << 28)) {
+        err = "more than 2^28 objects";
+        return RTX_ERR_CAPACITY;
+    }
+    out.xforms.resize(d.n_xforms);
+    for (uint32_t i = 0; i < d.n_xforms; i++) {
+        std::memcpy(out.xforms[i].o2w, d.xforms + (size_t)i * 32, 64);
+        std::memcpy(out.xforms[i].w2o, d.xforms + (size_t)i * 32 + 16, 64);
+    }
+    // materials
+    out.mats.resize(d.n_materials);
+    std::vector<uint32_t> mat_bounce(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; i++) {
+        MaterialRec &m = out.mats[i];
+        m.prog_first = (uint32_t)out.prog.size();
+        uint32_t nb = 0;
+        int rc = emit_material(d, d.mat_root[i], 0, out.prog, nb, err);
+        if (rc != RTX_OK) return rc;
+        if (nb > (uint32_t)MAX_BOUNCE_LEAVES) {
+            err = "material with more than 4 reflective/refractive leaves";
+            return RTX_ERR_CAPACITY;
+        }
+        m.prog_count = (uint32_t)out.prog.size() - m.prog_first;
+        m.n_bounce = nb;
+        mat_bounce[i] = nb;
+        m.tex_kind = (uint32_t)d.mat_tex_kind[i];
+        m.tex_id = (uint32_t)d.mat_tex_id[i];
+        if (m.tex_kind == RTX_TEX_IMAGE && m.tex_id >= d.n_textures) {
+            err = "texture index out of range";
+            return RTX_ERR_INVALID;
+        }
+        for (int k = 0; k < 3; k++) {  // Color::rgb clamps on construction (color.rs:17-23)
+            float c = d.mat_tex_color[i * 3 + k];
+            m.tex_color[k] = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+        }
+    }
+    // textures
+    size_t tex_bytes = 0;
+    out.tex.resize(d.n_textures);
+    for (uint32_t i = 0; i < d.n_textures; i++) {
+        if (d.tex_w[i] <= 0 || d.tex_h[i] <= 0) {
+            err = "empty texture";
+            return RTX_ERR_INVALID;
+        }
+        out.tex[i].w = (uint32_t)d.tex_w[i];
+        out.tex[i].h = (uint32_t)d.tex_h[i];
+        out.tex[i].offset = d.tex_offset[i];
+        size_t end = d.tex_offset[i] + (size_t)d.tex_w[i] * d.tex_h[i] * 3;
+        if (end > tex_bytes) tex_bytes = end;
+    }
+    if (tex_bytes) out.tex_data.assign(d.tex_data, d.tex_data + tex_bytes);
+    // lights
+    out.lights.resize(d.n_lights);
+    for (uint32_t i = 0; i < d.n_lights; i++) {
+        LightRec &l = out.lights[i];
+        l.type = (uint32_t)d.light_type[i];
+        for (int k = 0; k < 3; k++) {
+            l.pos[k] = d.light_pos[i * 3 + k];
+            l.dir[k] = d.light_dir[i * 3 + k];
+            float c = d.light_color[i * 3 + k];
+            l.color[k] = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+        }
+        l.angle_deg = d.light_angle_deg[i];
+        l.pad = 0;
+    }
+    // primitives in leaf order
+    uint32_t n = d.n_objects;
+    out.prims.resize(n);
+    out.prim_obj = bvh.leaf_order;
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t o = bvh.leaf_order[k];
+        const float *v = d.obj_verts + (size_t)o * 12;
+        Prim &p = out.prims[k];
+        std::memset(&p, 0, sizeof(p));
+        int type = d.obj_type[o];
+        int xf = d.obj_xform[o], mat = d.obj_material[o];
+        if (type < 0 || type > 2 || xf < 0 || (uint32_t)xf >= d.n_xforms || mat < 0 || (uint32_t)mat >= d.n_materials) {
+            err = "object with bad type / transform / material index";
+            return RTX_ERR_INVALID;
+        }
+        if (type == RTX_OBJ_SPHERE) {
+            p.v[0] = v[0];
+            p.v[1] = v[1];
+            p.v[2] = v[2];
+            p.v[3] = v[3];
+            p.v[4] = v[3] * v[3];  // radius.powf(2.0) (object.rs:154)
+        } else {
+            int nv = type == RTX_OBJ_QUAD ? 12 : 9;
+            for (int j = 0; j < nv; j++) p.v[j] = v[j];
+            V3 a = v3(v[0], v[1], v[2]), b = v3(v[3], v[4], v[5]);
+            V3 e = type == RTX_OBJ_QUAD ? v3(v[9], v[10], v[11]) : v3(v[6], v[7], v[8]);
+            V3 nn = normalize(cross(b - a, e - a));  // object.rs:168,191
+            p.n[0] = nn.x;
+            p.n[1] = nn.y;
+            p.n[2] = nn.z;
+        }
+        p.meta = (uint32_t)type | ((uint32_t)xf << 2) | ((uint32_t)mat << 16);
+        if (mat_bounce[mat] > out.max_bounce) out.max_bounce = mat_bounce[mat];
+    }
+    // tree
+    if (!bvh.nodes.empty()) {
+        Emit e{bvh, out};
+        out.nodes.reserve(bvh.nodes.size() / 2 + 1);
+        float total = 0.0f;
+        out.root_ref = e.emit(0, total);
+        out.total_sa = total;
+        for (int k = 0; k < 3; k++) {
+            out.root_mn[k] = bvh.nodes[0].mn[k];
+            out.root_mx[k] = bvh.nodes[0].mx[k];
+        }
+    }
+    return RTX_OK;
+}
+
+}  // namespace rtx

@@ -1,0 +1,31 @@
+// Flattens the host scene + built BVH into the 64-byte records the kernels traverse.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "device_types.h"
+
+namespace rtx {
+
+struct FlatScene {
+    std::vector<BvhNode> nodes;         // internal nodes, DFS preorder (root = 0)
+    std::vector<Prim> prims;            // leaf order
+    std::vector<uint32_t> prim_obj;     // leaf order -> object index
+    std::vector<Xform> xforms;
+    std::vector<MaterialRec> mats;
+    std::vector<MatInstr> prog;
+    std::vector<TextureRec> tex;
+    std::vector<uint8_t> tex_data;
+    std::vector<LightRec> lights;
+    std::vector<uint32_t> preorder_sizes;  // object count of every tree node, preorder (digest)
+    uint32_t root_ref = NO_PRIM;
+    float root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
+    uint32_t n_leaves = 0;
+    uint32_t max_bounce = 0;            // largest number of bounce leaves of any material in use
+    float total_sa = 0.0f;              // BvhTree::total_sa (bvh.rs:419-426)
+};
+
+int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err);
+
+}  // namespace rtx

@@ -1,0 +1,89 @@
+// Launch interface between the host API (rtx_api.cpp) and the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace rtx {
+
+// Scene as the kernels see it: pointers into HBM plus the small constants.
+struct DeviceScene {
+    const BvhNode *nodes;
+    const Prim *prims;
+    const Xform *xforms;
+    const MaterialRec *mats;
+    const MatInstr *prog;
+    const TextureRec *tex;
+    const uint8_t *tex_data;
+    const LightRec *lights;
+    const uint32_t *prim_obj;   // leaf-order primitive -> object index of the description
+    uint32_t n_prims, n_lights;
+    uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
+    float root_mn[3], root_mx[3];
+    float coord_scale;          // largest |coordinate| of the root box (pruning slack)
+    float background[3];
+    float c2w[16];
+    uint32_t width, height;
+};
+
+// Counter block (uint32 words) in device memory, zeroed before every batch.
+enum {
+    CTR_LEVEL_COUNT = 0,    // [8]  path nodes per bounce level
+    CTR_SHADOW_COUNT = 8,   // [8][MAX_LIGHTS] shadow-queue entries per level and light
+    CTR_OVERFLOW = 8 + 8 * MAX_LIGHTS,
+    CTR_VISIT_NODES_LO = CTR_OVERFLOW + 1,  // 64-bit visit counters as lo/hi pairs
+    CTR_VISIT_NODES_HI,
+    CTR_VISIT_PRIMS_LO,
+    CTR_VISIT_PRIMS_HI,
+    CTR_WORDS = 160
+};
+
+// Wavefront state of one batch of primary samples ("path nodes": one per traced ray).
+struct Frame {
+    float4 *ray_o;      // xyz origin,    w = hit t
+    float4 *ray_d;      // xyz direction, w = bits of hit primitive (leaf order)
+    uint2 *link;        // x = lit-light mask, y = first bounce child (NO_PRIM: none)
+    float4 *color;      // resolved colour of the node
+    uint32_t *shadow_q; // [MAX_LIGHTS][q_cap] node ids waiting for a shadow query
+    uint32_t *counters; // CTR_WORDS
+    uint32_t *spill;    // traversal-stack overflow, [MAX_TREE_DEPTH-LDS_STACK][threads]
+    uint32_t node_cap, q_cap;
+};
+
+struct BatchInfo {
+    uint32_t q0, npix;      // local pixel slots [q0, q0+npix) of this rank
+    uint32_t s0, ns;        // samples [s0, s0+ns)
+    uint32_t spp;           // total samples per pixel of the render
+    uint32_t use_jitter;
+    uint32_t seed_lo, seed_hi;
+    uint32_t tile, rank, nranks, tiles_x, tiles_y;
+    uint32_t max_levels;    // = max_ray_bounces
+};
+
+struct LaunchCfg {
+    hipStream_t stream;
+    int persistent_blocks;  // grid of the persistent trace kernels
+    bool count_visits;
+    bool reference_traversal;
+};
+
+void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, const LaunchCfg &lc);
+void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
+void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level, uint32_t max_levels,
+                          const LaunchCfg &lc);
+void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
+// Adds the batch's sample colours to `sum` in sample order (world.rs:54-61); on the last
+// sample chunk divides by spp, clamps and quantises (world.rs:62-63, color.rs:25-31).
+void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum,
+                       uint8_t *tiles_rgb8, float *tiles_f32_or_null, const LaunchCfg &lc);
+// Hit export for rtx_trace_primary / rtx_trace_rays: level-0 nodes -> (object id, t).
+void launch_export_hits(const DeviceScene &sc, const Frame &fr, uint32_t n, uint32_t *out_obj, float *out_t,
+                        const LaunchCfg &lc);
+// Loads caller rays (origin, direction) into level 0, normalising as Ray::new does.
+void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc);
+void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc);
+int query_persistent_blocks(int device);
+
+}  // namespace rtx

@@ -1,0 +1,910 @@
+// HIP kernels of the trace path for gfx950 (wave64).  Build with -ffp-contract=off: every
+// f32 operation that decides a hit (box slab test, primitive predicates, world t) is the
+// same IEEE operation in the same order as the reference's Rust code, so hit ids and t
+// come out bit-identical; only libm calls (atan2/acos/pow) differ in the last ulp.
+//
+//   raygen          camera.rs:32-47 + the spp loop of world.rs:54-61
+//   trace_closest   bvh.rs:60-131,359-395 + object.rs:145-220   (persistent, per-lane stack in LDS)
+//   shade_forward   world.rs:118-125 (hit point, shadow-ray list) + material.rs:185-203 (bounce rays),
+//                   queues compacted with wave ballot / prefix sum
+//   trace_shadow    light.rs:81-122 as an any-hit query
+//   resolve         material.rs:53-76,98-206,220-240 + color.rs (clamped algebra), bottom-up
+//   accumulate      world.rs:61-63 + color.rs:25-31
+#include "kernels.h"
+
+namespace rtx {
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// ---------------------------------------------------------------- cgmath-order arithmetic
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float magnitude(F3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ F3 normalize(F3 a) { return a * (1.0f / magnitude(a)); }
+__device__ __forceinline__ float angle_rad(F3 a, F3 b) { return atan2f(magnitude(cross(a, b)), dot(a, b)); }
+__device__ __forceinline__ F3 transform_point(const float *M, F3 p) {
+    float h[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = ((M[r] * p.x + M[4 + r] * p.y) + M[8 + r] * p.z) + M[12 + r] * 1.0f;
+    float iw = 1.0f / h[3];
+    return f3(h[0] * iw, h[1] * iw, h[2] * iw);
+}
+__device__ __forceinline__ F3 transform_vector(const float *M, F3 v) {
+    float h[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) h[r] = ((M[r] * v.x + M[4 + r] * v.y) + M[8 + r] * v.z) + M[12 + r] * 0.0f;
+    return f3(h[0], h[1], h[2]);
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {  // utils.rs:5-13
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return normalize(v - 2.0f * dot(v, n) * n); }  // utils.rs:15-17
+__device__ __forceinline__ F3 refract(F3 v, F3 normal, float idx) {  // utils.rs:46-59
+    float n = dot(v, normal) <= 0.0f ? 1.0f / idx : idx / 1.0f;
+    float cos_in = fabsf(dot(v, normal));
+    float cos_out = sqrtf(1.0f - (n * n) * (1.0f - (cos_in * cos_in)));  // powf(x, 2.0) == x*x
+    return normalize(v * n + (n * cos_in - cos_out) * normal);
+}
+__device__ __forceinline__ F3 crgb(float r, float g, float b) {  // Color::rgb (color.rs:17-23)
+    return f3(clampf(r, 0.0f, 1.0f), clampf(g, 0.0f, 1.0f), clampf(b, 0.0f, 1.0f));
+}
+__device__ __forceinline__ F3 cadd(F3 a, F3 b) { return crgb(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 cmul(F3 a, F3 b) { return crgb(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 cscale(F3 a, float s) { return crgb(a.x * s, a.y * s, a.z * s); }
+
+constexpr float DEG_TO_RAD = (float)(3.14159265358979323846 / 180.0);
+constexpr float RAD_TO_DEG = (float)(180.0 / 3.14159265358979323846);
+constexpr float PI_F = 3.14159265358979323846f;
+
+// ---------------------------------------------------------------- jitter (same definition as the oracle)
+__device__ __forceinline__ uint32_t pcg(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+__device__ __forceinline__ uint32_t jitter_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t px, uint32_t py,
+                                               uint32_t sample, uint32_t dim) {
+    uint32_t h = pcg(seed_lo ^ 0x9E3779B9u);
+    h = pcg(h ^ seed_hi);
+    h = pcg(h + px);
+    h = pcg(h + py);
+    h = pcg(h + sample * 2u + dim);
+    return h;
+}
+
+// ---------------------------------------------------------------- wave-level queue allocation
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// One slot per lane with pred set: ballot + popcount prefix, one atomic per wave.
+__device__ __forceinline__ uint32_t wave_alloc1(uint32_t *counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    uint32_t lane = lane_id();
+    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + prefix;
+}
+// n slots per lane (n small): shuffle prefix sum across the wave, one atomic per wave.
+__device__ __forceinline__ uint32_t wave_allocn(uint32_t *counter, uint32_t n) {
+    uint32_t lane = lane_id();
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) return 0;
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
+__device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t level) {
+    uint32_t b = 0;
+    for (uint32_t j = 0; j < level; j++) b += ctr[CTR_LEVEL_COUNT + j];
+    return b;
+}
+
+// ---------------------------------------------------------------- ray state for traversal
+struct RayCtx {
+    F3 o, d;        // world ray (d normalised by Ray::new)
+    F3 inv;         // 1/d, correctly rounded
+    F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
+    uint32_t xf;
+    bool exact_only;  // a zero / non-finite component: always take the division path
+    float slack0;     // absolute pruning slack
+};
+
+__device__ __forceinline__ void set_xform(RayCtx &r, const Xform *xforms, uint32_t xf) {
+    const float *M = xforms[xf].w2o;
+    r.oo = transform_point(M, r.o);
+    r.od = normalize(transform_vector(M, r.d));
+    r.xf = xf;
+}
+
+__device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o, F3 d) {
+    r.o = o;
+    r.d = d;
+    r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool fin = isfinite(r.inv.x) && isfinite(r.inv.y) && isfinite(r.inv.z) && isfinite(o.x) && isfinite(o.y) &&
+               isfinite(o.z);
+    r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
+    float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    r.slack0 = 1.5e-5f * (sc.coord_scale + m);
+    set_xform(r, sc.xforms, 0);
+}
+
+// AABB::intersect decision exactly as bvh.rs:60-131 (true divisions, Interval algebra in
+// the reference's nesting order x ∩ (y ∩ z)).
+struct Ival {
+    int kind;  // 0 Infinite, 1 Closed, 2 Empty
+    float a, b;
+};
+__device__ __forceinline__ Ival ival_new(float a, float b, float x, float slope) {
+    Ival r;
+    if (slope == 0.0f) {
+        r.kind = (a <= x && x <= b) ? 0 : 2;
+        r.a = r.b = 0.0f;
+        return r;
+    }
+    float ta = (a - x) / slope, tb = (b - x) / slope;
+    r.kind = 1;
+    r.a = fminf(ta, tb);
+    r.b = fmaxf(ta, tb);
+    return r;
+}
+__device__ __forceinline__ Ival ival_intersect(Ival s, Ival o) {
+    if (s.kind == 0) return o;
+    if (s.kind == 2) return s;
+    if (o.kind == 0) return s;
+    if (o.kind == 2) return o;
+    Ival r;
+    r.a = fmaxf(s.a, o.a);
+    r.b = fminf(s.b, o.b);
+    r.kind = (r.a <= r.b) ? 1 : 2;
+    return r;
+}
+__device__ __noinline__ bool box_exact(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 d,
+                                       float &tmin, float &tmax) {
+    Ival xi = ival_new(mnx, mxx, o.x, d.x);
+    Ival yi = ival_new(mny, mxy, o.y, d.y);
+    Ival zi = ival_new(mnz, mxz, o.z, d.z);
+    Ival t = ival_intersect(xi, ival_intersect(yi, zi));
+    if (t.kind == 2) return false;
+    if (t.kind == 1) {
+        tmin = t.a;
+        tmax = t.b;
+    } else {  // unreachable!() in the reference
+        tmin = -INFINITY;
+        tmax = INFINITY;
+    }
+    return true;
+}
+
+// Box decision + pruning.  The fast path multiplies by the reciprocal; its result can
+// differ from the division by < 2^-22 relative, so only clearly separated intervals are
+// decided there and the rest re-run the reference's divisions.  Pruning (behind the
+// origin / beyond the best hit) keeps a slack far above the f32 error of t.
+template <bool REF>
+__device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                         const RayCtx &r, float limit_plus, float &t_entry) {
+    float tmin, tmax;
+    bool hit;
+    if (!r.exact_only) {
+        float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
+        float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
+        float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
+        tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
+        if (tmin <= tmax - delta) hit = true;
+        else if (tmin > tmax + delta) hit = false;
+        else hit = box_exact(mnx, mny, mnz, mxx, mxy, mxz, r.o, r.d, tmin, tmax);
+    } else {
+        hit = box_exact(mnx, mny, mnz, mxx, mxy, mxz, r.o, r.d, tmin, tmax);
+    }
+    t_entry = tmin;
+    if (REF) return hit;
+    return hit && !(tmax < -r.slack0) && !(tmin > limit_plus);
+}
+
+// Object::get_intersection (object.rs:145-220) against one 64-byte primitive record.
+__device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const Xform *xforms, float &t_world) {
+    const float4 *q4 = reinterpret_cast<const float4 *>(pp);
+    float4 p0 = q4[0], p1 = q4[1], p2 = q4[2], p3 = q4[3];
+    uint32_t meta = __float_as_uint(p3.w);
+    uint32_t type = meta & 3u, xf = (meta >> 2) & 0x3FFFu;
+    if (xf != r.xf) set_xform(r, xforms, xf);
+    F3 position = r.oo, direction = r.od;
+    float t;
+    bool hit = false;
+    if (type == 0u) {  // Sphere: centre p0.xyz, radius p0.w, radius^2 p1.x
+        F3 center = f3(p0.x, p0.y, p0.z);
+        float tc = dot(center - position, direction);
+        F3 closest = position + tc * direction;
+        float radius_sqrd = p1.x;
+        F3 cd = center - closest;
+        float dist_sqrd = dot(cd, cd);
+        if (dist_sqrd <= radius_sqrd) {
+            float delta = sqrtf(radius_sqrd - dist_sqrd);
+            float c0 = tc - delta, c1 = tc + delta;
+            bool s0 = !signbit(c0), s1 = !signbit(c1);
+            if (s0 && s1) {
+                t = (c0 > c1) ? c1 : c0;
+                hit = true;
+            } else if (s0) {
+                t = c0;
+                hit = true;
+            } else if (s1) {
+                t = c1;
+                hit = true;
+            }
+        }
+    } else {
+        F3 a = f3(p0.x, p0.y, p0.z), b = f3(p0.w, p1.x, p1.y), c = f3(p1.z, p1.w, p2.x);
+        F3 normal = f3(p3.x, p3.y, p3.z);
+        float dn = dot(direction, normal);
+        if (dn < 0.0f) {
+            float tt = dot(a - position, normal) / dn;
+            if (tt > 0.0f) {
+                F3 q = position + tt * direction;
+                float e0 = dot(cross(b - a, q - a), normal);
+                float e1 = dot(cross(c - b, q - b), normal);
+                bool inside = !signbit(e0) && !signbit(e1);
+                if (type == 2u) {  // Quad (object.rs:167-189)
+                    F3 d = f3(p2.y, p2.z, p2.w);
+                    float e2 = dot(cross(d - c, q - c), normal);
+                    float e3 = dot(cross(a - d, q - d), normal);
+                    inside = inside && !signbit(e2) && !signbit(e3);
+                } else {  // Triangle (object.rs:190-211)
+                    float e2 = dot(cross(a - c, q - c), normal);
+                    inside = inside && !signbit(e2);
+                }
+                if (inside) {
+                    t = tt;
+                    hit = true;
+                }
+            }
+        }
+    }
+    if (!hit) return false;
+    F3 osp = position + t * direction;                 // object.rs:214
+    F3 wp = transform_point(xforms[xf].o2w, osp);      // object.rs:216-217
+    t_world = dot(wp - r.o, r.d);                      // object.rs:218 / ray.rs:31-33
+    return true;
+}
+
+// ---------------------------------------------------------------- BVH traversal
+// MODE 0: closest hit, ties resolved by (t, leaf-order index) = the reference's
+//         "first minimum wins" over its left-to-right recursion (bvh.rs:367-371,385-389).
+// MODE 1: light.rs:81-97 as any-hit: stop at the first hit with t + 1e-4 < dist;
+//         otherwise report whether anything was hit at all.
+// MODE 2: directional light (light.rs:106-112): stop at the first hit.
+struct TravOut {
+    uint32_t prim;
+    float t;
+    bool any, occluded;
+    uint32_t nodes, prims;
+};
+
+template <int MODE, bool COUNT, bool REF>
+__device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, uint32_t *lds, uint32_t *spill,
+                                         uint32_t spill_stride, float dist, TravOut &out) {
+    out.prim = NO_PRIM;
+    out.t = INFINITY;
+    out.any = false;
+    out.occluded = false;
+    out.nodes = 0;
+    out.prims = 0;
+    uint32_t cur = sc.root_ref;
+    if (cur == NO_PRIM) return;
+    float limit_plus = INFINITY;
+    {
+        float te;
+        if (!box_test<REF>(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], r,
+                           limit_plus, te))
+            return;
+    }
+    int sp = 0;
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) out.nodes++;
+            float tl, tr;
+            bool hl = box_test<REF>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, tl);
+            bool hr = box_test<REF>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, tr);
+            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            if (hl && hr) {
+                uint32_t near = left, far = right;
+                if (!REF && tr < tl) {
+                    near = right;
+                    far = left;
+                }
+                if (sp < LDS_STACK) lds[sp * BLOCK] = far;
+                else spill[(size_t)(sp - LDS_STACK) * spill_stride] = far;
+                sp++;
+                cur = near;
+                continue;
+            }
+            if (hl) {
+                cur = left;
+                continue;
+            }
+            if (hr) {
+                cur = right;
+                continue;
+            }
+        } else {
+            uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
+            bool stop = false;
+            for (uint32_t k = 0; k < cnt; k++) {
+                float tw;
+                if (COUNT) out.prims++;
+                if (prim_intersect(sc.prims + first + k, r, sc.xforms, tw)) {
+                    if (MODE == 0) {
+                        uint32_t pi = first + k;
+                        if (!out.any || tw < out.t || (tw == out.t && pi < out.prim)) {
+                            out.any = true;
+                            out.t = tw;
+                            out.prim = pi;
+                            limit_plus = tw + (r.slack0 + 1.5e-5f * fabsf(tw));
+                        }
+                    } else if (MODE == 1) {
+                        out.any = true;
+                        if (tw + 1e-4f < dist) {
+                            out.occluded = true;
+                            stop = true;
+                            break;
+                        }
+                        limit_plus = dist + (r.slack0 + 1.5e-5f * fabsf(dist));
+                    } else {
+                        out.any = true;
+                        out.occluded = true;
+                        stop = true;
+                        break;
+                    }
+                }
+            }
+            if (stop) break;
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = (sp < LDS_STACK) ? lds[sp * BLOCK] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
+    }
+}
+
+__device__ __forceinline__ void add_visits(uint32_t *ctr, uint32_t nodes, uint32_t prims) {
+    // wave reduction, then one 64-bit atomic pair per wave
+    for (int d = 32; d > 0; d >>= 1) {
+        nodes += __shfl_down(nodes, d, 64);
+        prims += __shfl_down(prims, d, 64);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + CTR_VISIT_NODES_LO), (unsigned long long)nodes);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + CTR_VISIT_PRIMS_LO), (unsigned long long)prims);
+    }
+}
+
+// ---------------------------------------------------------------- raygen
+__device__ __forceinline__ bool slot_to_pixel(const BatchInfo &bi, uint32_t width, uint32_t height, uint32_t lp,
+                                              uint32_t &px, uint32_t &py, uint32_t &tile_off) {
+    uint32_t T = bi.tile, tt = T * T;
+    uint32_t lt = lp / tt, rr = lp % tt;
+    uint32_t blk = rr >> 6, in = rr & 63u, bpr = T >> 3;
+    uint32_t x_in = (blk % bpr) * 8u + (in & 7u), y_in = (blk / bpr) * 8u + (in >> 3);
+    uint32_t gt = lt * bi.nranks + bi.rank;
+    tile_off = lt * tt + y_in * T + x_in;
+    if (gt >= bi.tiles_x * bi.tiles_y) return false;
+    px = (gt % bi.tiles_x) * T + x_in;
+    py = (gt / bi.tiles_x) * T + y_in;
+    return px < width && py < height;
+}
+
+__global__ void __launch_bounds__(BLOCK) raygen_kernel(DeviceScene sc, Frame fr, BatchInfo bi) {
+    uint32_t n = bi.npix * bi.ns;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) fr.counters[CTR_LEVEL_COUNT] = n;
+    if (i >= n) return;
+    uint32_t q = i % bi.npix, sl = i / bi.npix;
+    uint32_t px, py, toff;
+    bool valid = slot_to_pixel(bi, sc.width, sc.height, bi.q0 + q, px, py, toff);
+    if (!valid) {
+        fr.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        fr.ray_d[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(INVALID_PRIM));
+        return;
+    }
+    // Camera::generate_ray (camera.rs:32-47)
+    float dx = 0.0f, dy = 0.0f;
+    if (bi.use_jitter) {
+        uint32_t s = bi.s0 + sl;
+        dx = ((float)(jitter_u32(bi.seed_lo, bi.seed_hi, px, py, s, 0) >> 8) * (1.0f / 16777216.0f)) / 2.0f;
+        dy = ((float)(jitter_u32(bi.seed_lo, bi.seed_hi, px, py, s, 1) >> 8) * (1.0f / 16777216.0f)) / 2.0f;
+    }
+    float x = ((float)px + dx) / (float)sc.width - 0.5f;
+    float y = 0.5f - ((float)py + dy) / (float)sc.height;
+    F3 pos = f3(x, y, -1.0f);
+    F3 dir = normalize(f3(x, y, -1.0f));
+    F3 wo = transform_point(sc.c2w, pos);
+    F3 wd = normalize(transform_vector(sc.c2w, dir));
+    fr.ray_o[i] = make_float4(wo.x, wo.y, wo.z, 0.0f);
+    fr.ray_d[i] = make_float4(wd.x, wd.y, wd.z, __uint_as_float(NO_PRIM));
+}
+
+__global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float *org_dir, uint32_t n) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) fr.counters[CTR_LEVEL_COUNT] = n;
+    if (i >= n) return;
+    const float *p = org_dir + (size_t)i * 6;
+    F3 d = normalize(f3(p[3], p[4], p[5]));  // Ray::new (ray.rs:11-16)
+    fr.ray_o[i] = make_float4(p[0], p[1], p[2], 0.0f);
+    fr.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(NO_PRIM));
+}
+
+// ---------------------------------------------------------------- trace_closest
+template <bool COUNT, bool REF>
+__global__ void __launch_bounds__(BLOCK) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ uint32_t lds_stack[LDS_STACK * BLOCK];
+    const uint32_t base = level_base(fr.counters, level);
+    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
+    const uint32_t nthreads = gridDim.x * BLOCK;
+    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t *lds = lds_stack + threadIdx.x;
+    uint32_t *spill = fr.spill + gtid;
+    uint32_t vn = 0, vp = 0;
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
+        uint32_t i = i0 + threadIdx.x;
+        if (i >= count) continue;
+        uint32_t node = base + i;
+        float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+        if (__float_as_uint(d4.w) == INVALID_PRIM) continue;
+        RayCtx r;
+        init_ray(r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
+        TravOut out;
+        traverse<0, COUNT, REF>(sc, r, lds, spill, nthreads, 0.0f, out);
+        fr.ray_o[node].w = out.any ? out.t : 0.0f;
+        fr.ray_d[node].w = __uint_as_float(out.prim);
+        if (COUNT) {
+            vn += out.nodes;
+            vp += out.prims;
+        }
+    }
+    if (COUNT) add_visits(fr.counters, vn, vp);
+}
+
+// ---------------------------------------------------------------- object.rs helpers for shading
+struct PrimView {
+    float4 p0, p1, p2, p3;
+    uint32_t type, xf, mat;
+};
+__device__ __forceinline__ PrimView load_prim(const Prim *pp) {
+    const float4 *q4 = reinterpret_cast<const float4 *>(pp);
+    PrimView v;
+    v.p0 = q4[0];
+    v.p1 = q4[1];
+    v.p2 = q4[2];
+    v.p3 = q4[3];
+    uint32_t meta = __float_as_uint(v.p3.w);
+    v.type = meta & 3u;
+    v.xf = (meta >> 2) & 0x3FFFu;
+    v.mat = meta >> 16;
+    return v;
+}
+// Object::get_normal (object.rs:225-235)
+__device__ __forceinline__ F3 object_normal(const PrimView &v, const Xform *xforms, F3 point) {
+    F3 n;
+    if (v.type == 0u) {
+        F3 p = transform_point(xforms[v.xf].w2o, point);
+        n = normalize(p - f3(v.p0.x, v.p0.y, v.p0.z));
+    } else {
+        n = f3(v.p3.x, v.p3.y, v.p3.z);
+    }
+    return normalize(transform_vector(xforms[v.xf].o2w, n));
+}
+// Object::get_uv (object.rs:255-278)
+__device__ __forceinline__ void object_uv(const PrimView &v, const Xform *xforms, F3 point, float &u, float &w) {
+    F3 p = transform_point(xforms[v.xf].w2o, point);
+    if (v.type == 0u) {
+        F3 n = normalize(p - f3(v.p0.x, v.p0.y, v.p0.z));
+        float theta = acosf(n.z);
+        float phi = atan2f(n.y, n.x);
+        u = theta / (2.0f * PI_F);
+        w = phi / PI_F;
+    } else {
+        F3 a = f3(v.p0.x, v.p0.y, v.p0.z), b = f3(v.p0.w, v.p1.x, v.p1.y);
+        F3 e = (v.type == 2u) ? f3(v.p2.y, v.p2.z, v.p2.w) : f3(v.p1.z, v.p1.w, v.p2.x);
+        F3 ba = b - a, ea = e - a;
+        u = dot(ba, p - a) / dot(ba, ba);
+        w = dot(ea, p - a) / dot(ea, ea);
+    }
+}
+
+// ---------------------------------------------------------------- shade_forward
+// For every hit of this level: the shadow queries of world.rs:121-125 are queued per light
+// (cone pre-test of light.rs:113-116 applied here), and the bounce rays of
+// material.rs:185-203 are appended to the next level's queue.
+__global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Frame fr, uint32_t level,
+                                                              uint32_t max_levels) {
+    const uint32_t base = level_base(fr.counters, level);
+    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
+    const uint32_t next_base = base + count;
+    const uint32_t nthreads = gridDim.x * BLOCK;
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
+        uint32_t i = i0 + threadIdx.x;
+        bool active = i < count;
+        uint32_t node = base + (active ? i : 0);
+        float4 o4 = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 0, 0);
+        uint32_t prim = NO_PRIM;
+        if (active) {
+            o4 = fr.ray_o[node];
+            d4 = fr.ray_d[node];
+            prim = __float_as_uint(d4.w);
+        }
+        bool hit = active && prim < INVALID_PRIM;
+        F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
+        F3 p = o + o4.w * d;  // ray.get_point_on_ray(t) (world.rs:120)
+        uint32_t lit = 0;
+        for (uint32_t l = 0; l < sc.n_lights; l++) {
+            const LightRec &L = sc.lights[l];
+            bool want = false;
+            if (hit) {
+                if (L.type == LIGHT_AMBIENT) lit |= 1u << l;
+                else if (L.type == 3u) {
+                    F3 ld = p - f3(L.pos[0], L.pos[1], L.pos[2]);
+                    want = !(angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), ld) > L.angle_deg * DEG_TO_RAD);
+                } else want = true;
+            }
+            uint32_t slot = wave_alloc1(fr.counters + CTR_SHADOW_COUNT + level * MAX_LIGHTS + l, want);
+            if (want) {
+                if (slot < fr.q_cap) fr.shadow_q[(size_t)l * fr.q_cap + slot] = node;
+                else fr.counters[CTR_OVERFLOW] = 1;
+            }
+        }
+        uint32_t nb = 0;
+        PrimView pv;
+        MaterialRec m;
+        if (hit) {
+            pv = load_prim(sc.prims + prim);
+            m = sc.mats[pv.mat];
+            if (level + 1 < max_levels) nb = m.n_bounce;
+        }
+        uint32_t off = wave_allocn(fr.counters + CTR_LEVEL_COUNT + level + 1, nb);
+        uint32_t child = NO_PRIM;
+        if (nb) {
+            if (next_base + off + nb <= fr.node_cap) {
+                child = next_base + off;
+                F3 normal = object_normal(pv, sc.xforms, p);
+                for (uint32_t k = 0; k < m.prog_count; k++) {
+                    const MatInstr &ins = sc.prog[m.prog_first + k];
+                    if (ins.op != OP_REFLECT && ins.op != OP_REFRACT) continue;
+                    F3 nd = (ins.op == OP_REFLECT) ? reflect(d, normal) : refract(d, normal, ins.p0);
+                    // Ray::new(p, nd).offset(1e-4) (material.rs:189-191, ray.rs:43-46)
+                    F3 rd = normalize(nd);
+                    F3 ro = p + 1e-4f * rd;
+                    rd = normalize(rd);
+                    uint32_t cn = child + ins.arg;
+                    fr.ray_o[cn] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                    fr.ray_d[cn] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(NO_PRIM));
+                }
+            } else {
+                fr.counters[CTR_OVERFLOW] = 1;
+            }
+        }
+        if (active) fr.link[node] = make_uint2(lit, child);
+    }
+}
+
+// ---------------------------------------------------------------- trace_shadow
+template <bool COUNT, bool REF>
+__global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ uint32_t lds_stack[LDS_STACK * BLOCK];
+    const uint32_t nthreads = gridDim.x * BLOCK;
+    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t *lds = lds_stack + threadIdx.x;
+    uint32_t *spill = fr.spill + gtid;
+    uint32_t vn = 0, vp = 0;
+    for (uint32_t l = 0; l < sc.n_lights; l++) {
+        const LightRec &L = sc.lights[l];
+        if (L.type == LIGHT_AMBIENT) continue;
+        uint32_t count = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
+        if (count > fr.q_cap) count = fr.q_cap;
+        const uint32_t *q = fr.shadow_q + (size_t)l * fr.q_cap;
+        F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
+        F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
+        for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
+            uint32_t i = i0 + threadIdx.x;
+            if (i >= count) continue;
+            uint32_t node = q[i];
+            float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+            F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
+            RayCtx r;
+            TravOut out;
+            bool reaches;
+            if (L.type == 2u) {
+                // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
+                F3 rd = normalize(-ldir);
+                F3 ro = p + 1e-4f * rd;
+                rd = normalize(rd);
+                init_ray(r, sc, ro, rd);
+                traverse<2, COUNT, REF>(sc, r, lds, spill, nthreads, 0.0f, out);
+                reaches = !out.any;
+            } else {
+                // Light::in_shadow (light.rs:81-97)
+                F3 ldv = p - lpos;
+                F3 rd = normalize(ldv);
+                float dist = magnitude(lpos - p);
+                init_ray(r, sc, lpos, rd);
+                traverse<1, COUNT, REF>(sc, r, lds, spill, nthreads, dist, out);
+                reaches = out.any && !out.occluded;
+            }
+            if (reaches) atomicOr(&fr.link[node].x, 1u << l);
+            if (COUNT) {
+                vn += out.nodes;
+                vp += out.prims;
+            }
+        }
+    }
+    if (COUNT) add_visits(fr.counters, vn, vp);
+}
+
+// ---------------------------------------------------------------- resolve
+// Light::get_falloff_at (light.rs:58-79)
+__device__ __forceinline__ float falloff_at(const LightRec &L, F3 point) {
+    F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
+    F3 dv = lpos - point;
+    float d2 = dot(dv, dv);
+    if (L.type == 1u) return 5.0f / (0.001f + d2);
+    float angle_to_point = angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), point - lpos) * RAD_TO_DEG;
+    float angle_delta = L.angle_deg - angle_to_point;
+    float cone = clampf(angle_delta / 8.0f, 0.0f, 1.0f);
+    return cone * 5.0f / (0.001f + d2);
+}
+// MaterialType::get_phong_multiple (material.rs:98-113)
+__device__ __forceinline__ float phong_multiple(F3 to_light, F3 normal, F3 incoming, float kd, float ks, float sh) {
+    F3 rv = reflect(to_light, normal);
+    float spec = clampf(-dot(rv, incoming), 0.0f, 1.0f);
+    float diff = clampf(dot(to_light, normal), 0.0f, 1.0f);
+    return kd * diff + ks * powf(spec, sh);
+}
+// TextureType::sample (material.rs:53-76)
+__device__ __forceinline__ F3 texture_sample(const DeviceScene &sc, const MaterialRec &m, const PrimView &pv, F3 p) {
+    if (m.tex_kind == 2u) {
+        TextureRec tx = sc.tex[m.tex_id];
+        float width = (float)tx.w, height = (float)tx.h;
+        float u, v;
+        object_uv(pv, sc.xforms, p, u, v);
+        float ru = fmodf(u, 1.0f);
+        if (ru < 0.0f) ru = ru + 1.0f;
+        float rv = fmodf(v, 1.0f);
+        if (rv < 0.0f) rv = rv + 1.0f;
+        float x = truncf(ru * width), y = truncf(rv * height);
+        float xc = clampf(x, 0.0f, width - 1.0f), yc = clampf(y, 0.0f, height - 1.0f);
+        uint32_t xi = (xc == xc) ? (uint32_t)xc : 0u, yi = (yc == yc) ? (uint32_t)yc : 0u;
+        const uint8_t *px = sc.tex_data + tx.offset + ((size_t)yi * tx.w + xi) * 3;
+        return crgb((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    }
+    if (m.tex_kind == 1u) return f3(m.tex_color[0], m.tex_color[1], m.tex_color[2]);
+    return crgb(0.5f, 0.5f, 0.5f);
+}
+
+__global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    const uint32_t base = level_base(fr.counters, level);
+    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
+    const uint32_t nthreads = gridDim.x * BLOCK;
+    const F3 bg = f3(sc.background[0], sc.background[1], sc.background[2]);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += nthreads) {
+        uint32_t node = base + i;
+        float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+        uint32_t prim = __float_as_uint(d4.w);
+        F3 res;
+        if (prim == INVALID_PRIM) res = f3(0.f, 0.f, 0.f);
+        else if (prim == NO_PRIM) res = bg;  // world.rs:127-130
+        else {
+            uint2 lk = fr.link[node];
+            F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
+            F3 p = o + o4.w * d;
+            PrimView pv = load_prim(sc.prims + prim);
+            MaterialRec m = sc.mats[pv.mat];
+            F3 surface = texture_sample(sc, m, pv, p);  // material.rs:229-230
+            F3 normal = f3(0.f, 0.f, 0.f);
+            bool have_normal = false;
+            F3 acc[MAX_COMP_DEPTH];
+            int asp = 0;
+            F3 val = f3(0.f, 0.f, 0.f);
+            for (uint32_t k = 0; k < m.prog_count; k++) {
+                MatInstr ins = sc.prog[m.prog_first + k];
+                switch (ins.op) {
+                    case OP_BEGIN:
+                        if (asp < MAX_COMP_DEPTH) acc[asp] = f3(0.f, 0.f, 0.f);
+                        asp++;
+                        break;
+                    case OP_ITEM:
+                        if (asp >= 1 && asp <= MAX_COMP_DEPTH) acc[asp - 1] = cadd(acc[asp - 1], cscale(val, ins.p0));
+                        break;
+                    case OP_END:
+                        asp--;
+                        if (asp >= 0 && asp < MAX_COMP_DEPTH) val = acc[asp];
+                        break;
+                    case OP_PHONG: {  // material.rs:144-184
+                        if (!have_normal) {
+                            normal = object_normal(pv, sc.xforms, p);
+                            have_normal = true;
+                        }
+                        F3 sum = f3(0.f, 0.f, 0.f);
+                        for (uint32_t l = 0; l < sc.n_lights; l++) {
+                            if (!(lk.x & (1u << l))) continue;
+                            const LightRec &L = sc.lights[l];
+                            F3 lcol = f3(L.color[0], L.color[1], L.color[2]);
+                            F3 lc;
+                            if (L.type == LIGHT_AMBIENT) lc = lcol;
+                            else if (L.type == 2u) {
+                                float pm = phong_multiple(-f3(L.dir[0], L.dir[1], L.dir[2]), normal, d, ins.p0, ins.p1, ins.p2);
+                                lc = cscale(lcol, pm);
+                            } else {
+                                F3 light_dir = f3(L.pos[0], L.pos[1], L.pos[2]) - p;
+                                float fo = falloff_at(L, p);
+                                float pm = phong_multiple(normalize(light_dir), normal, d, ins.p0, ins.p1, ins.p2);
+                                lc = cscale(cscale(lcol, fo), pm);
+                            }
+                            sum = cadd(sum, cmul(surface, lc));
+                        }
+                        val = sum;
+                        break;
+                    }
+                    case OP_REFLECT:
+                    case OP_REFRACT: {
+                        if (lk.y != NO_PRIM) {
+                            float4 c = fr.color[lk.y + ins.arg];
+                            val = f3(c.x, c.y, c.z);
+                        } else {
+                            val = bg;  // trace_ray(.., 0) (world.rs:116-117)
+                        }
+                        break;
+                    }
+                    default: val = crgb(0.5f, 0.5f, 0.5f); break;  // material.rs:204
+                }
+            }
+            res = val;
+        }
+        fr.color[node] = make_float4(res.x, res.y, res.z, 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------- accumulate
+__global__ void __launch_bounds__(BLOCK) accumulate_kernel(DeviceScene sc, Frame fr, BatchInfo bi, float4 *sum,
+                                                           uint8_t *tiles_rgb8, float *tiles_f32) {
+    uint32_t q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= bi.npix) return;
+    uint32_t lp = bi.q0 + q;
+    float4 a = (bi.s0 == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : sum[lp];
+    for (uint32_t sl = 0; sl < bi.ns; sl++) {  // fold in sample order (world.rs:54-61)
+        float4 c = fr.color[(size_t)sl * bi.npix + q];
+        a.x = a.x + c.x;
+        a.y = a.y + c.y;
+        a.z = a.z + c.z;
+    }
+    if (bi.s0 + bi.ns < bi.spp) {
+        sum[lp] = a;
+        return;
+    }
+    uint32_t px, py, toff;
+    bool valid = slot_to_pixel(bi, sc.width, sc.height, lp, px, py, toff);
+    float n = (float)bi.spp;
+    F3 res = valid ? crgb(a.x / n, a.y / n, a.z / n) : f3(0.f, 0.f, 0.f);  // world.rs:62-63
+    // Color::get_rgb: (c * 255.0) as u8 (color.rs:25-31)
+    float v[3] = {res.x * 255.0f, res.y * 255.0f, res.z * 255.0f};
+    for (int k = 0; k < 3; k++) {
+        float f = v[k];
+        uint8_t b = (!(f == f) || f <= 0.0f) ? 0 : (f >= 255.0f ? 255 : (uint8_t)f);
+        tiles_rgb8[(size_t)toff * 3 + k] = b;
+    }
+    if (tiles_f32) {
+        tiles_f32[(size_t)toff * 3] = res.x;
+        tiles_f32[(size_t)toff * 3 + 1] = res.y;
+        tiles_f32[(size_t)toff * 3 + 2] = res.z;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) export_hits_kernel(DeviceScene sc, Frame fr, uint32_t n, uint32_t *out_obj,
+                                                            float *out_t) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t prim = __float_as_uint(fr.ray_d[i].w);
+    out_obj[i] = prim < INVALID_PRIM ? sc.prim_obj[prim] : 0xFFFFFFFFu;
+    out_t[i] = fr.ray_o[i].w;
+}
+__global__ void __launch_bounds__(BLOCK) export_colors_kernel(Frame fr, uint32_t n, float *out_rgb) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 c = fr.color[i];
+    out_rgb[(size_t)i * 3] = c.x;
+    out_rgb[(size_t)i * 3 + 1] = c.y;
+    out_rgb[(size_t)i * 3 + 2] = c.z;
+}
+
+inline int grid_for(uint32_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, const LaunchCfg &lc) {
+    uint32_t n = bi.npix * bi.ns;
+    hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, sc, fr, bi);
+}
+void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(load_rays_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, org_dir, n);
+}
+void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
+    dim3 g(lc.persistent_blocks), b(BLOCK);
+    if (lc.reference_traversal) {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_closest_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
+    } else {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
+    }
+}
+void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
+    dim3 g(lc.persistent_blocks), b(BLOCK);
+    if (lc.reference_traversal) {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_shadow_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
+    } else {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_shadow_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
+    }
+}
+void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level, uint32_t max_levels,
+                          const LaunchCfg &lc) {
+    hipLaunchKernelGGL(shade_forward_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level,
+                       max_levels);
+}
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(resolve_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level);
+}
+void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum, uint8_t *tiles_rgb8,
+                       float *tiles_f32, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(bi.npix ? bi.npix : 1)), dim3(BLOCK), 0, lc.stream, sc, fr, bi,
+                       sum, tiles_rgb8, tiles_f32);
+}
+void launch_export_hits(const DeviceScene &sc, const Frame &fr, uint32_t n, uint32_t *out_obj, float *out_t,
+                        const LaunchCfg &lc) {
+    hipLaunchKernelGGL(export_hits_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, sc, fr, n, out_obj,
+                       out_t);
+}
+void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(export_colors_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, n, out_rgb);
+}
+
+int query_persistent_blocks(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_closest_kernel<false, false>, BLOCK, 0) !=
+            hipSuccess ||
+        per_cu < 1)
+        per_cu = 4;
+    if (per_cu > 6) per_cu = 6;  // 24 KB of LDS stack per block
+    return prop.multiProcessorCount * per_cu;
+}
+
+}  // namespace rtx

@@ -1,0 +1,706 @@
+// C ABI of include/rtx.h: context, scene upload, wavefront render driver.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "../../include/rtx_host.h"
+#include "bvh_build.h"
+#include "flatten.h"
+#include "kernels.h"
+
+using namespace rtx;
+
+namespace {
+std::string g_init_error;
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int persistent_blocks = 1024;
+    // scene
+    bool has_scene = false;
+    DeviceScene ds{};
+    std::vector<void *> scene_allocs;
+    std::vector<uint32_t> leaf_order, preorder_sizes;
+    rtx_bvh_info info{};
+    uint32_t max_bounce = 0;
+    // wavefront state
+    Frame fr{};
+    std::vector<void *> frame_allocs;
+    uint64_t cap0 = 0, node_cap = 0, q_cap = 0;
+    uint32_t frame_lights = 0;
+    float4 *sum = nullptr;
+    uint8_t *tiles = nullptr;
+    float *tiles_f32 = nullptr;
+    uint64_t pix_cap = 0;
+    uint32_t *h_counters = nullptr;  // pinned, one CTR_WORDS block per batch
+    uint32_t h_counter_slots = 0;
+    std::vector<hipEvent_t> events;
+    uint64_t node_budget_bytes = 32ull << 30;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return RTX_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+template <class T>
+int upload(rtx_ctx *c, const std::vector<T> &v, const T **out, std::vector<void *> &allocs) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 64);
+    void *p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(p);
+    c->info.device_bytes += bytes;
+    return RTX_OK;
+}
+
+void free_all(std::vector<void *> &allocs) {
+    for (void *p : allocs) (void)hipFree(p);
+    allocs.clear();
+}
+
+struct Partition {
+    uint32_t tile, rank, nranks, tiles_x, tiles_y, my_tiles;
+    uint64_t npix;
+};
+
+int make_partition(rtx_ctx *c, const rtx_partition *p, Partition &out) {
+    out.tile = p ? p->tile : 32;
+    out.rank = p ? p->rank : 0;
+    out.nranks = p ? p->nranks : 1;
+    if (out.tile == 0 || (out.tile & 7u) || out.tile > 1024 || out.nranks == 0 || out.rank >= out.nranks) {
+        c->err = "partition: tile must be a multiple of 8 (<= 1024) and rank < nranks";
+        return RTX_ERR_INVALID;
+    }
+    out.tiles_x = (c->ds.width + out.tile - 1) / out.tile;
+    out.tiles_y = (c->ds.height + out.tile - 1) / out.tile;
+    uint64_t nt = (uint64_t)out.tiles_x * out.tiles_y;
+    out.my_tiles = (uint32_t)((nt + out.nranks - 1 - out.rank) / out.nranks);
+    out.npix = (uint64_t)out.my_tiles * out.tile * out.tile;
+    return RTX_OK;
+}
+
+// host mirror of slot_to_pixel in kernels.hip
+bool slot_to_pixel(const Partition &pt, uint32_t W, uint32_t H, uint64_t lp, uint32_t &px, uint32_t &py) {
+    uint32_t T = pt.tile, tt = T * T;
+    uint32_t lt = (uint32_t)(lp / tt), rr = (uint32_t)(lp % tt);
+    uint32_t blk = rr >> 6, in = rr & 63u, bpr = T >> 3;
+    uint32_t x_in = (blk % bpr) * 8u + (in & 7u), y_in = (blk / bpr) * 8u + (in >> 3);
+    uint64_t gt = (uint64_t)lt * pt.nranks + pt.rank;
+    if (gt >= (uint64_t)pt.tiles_x * pt.tiles_y) return false;
+    px = (uint32_t)(gt % pt.tiles_x) * T + x_in;
+    py = (uint32_t)(gt / pt.tiles_x) * T + y_in;
+    return px < W && py < H;
+}
+
+uint64_t geo_sum(uint32_t K, uint32_t levels) {
+    uint64_t s = 0, g = 1;
+    for (uint32_t k = 0; k < levels; k++) {
+        s += g;
+        g *= K;
+        if (K == 0) break;
+    }
+    return std::max<uint64_t>(s, 1);
+}
+uint64_t geo_last(uint32_t K, uint32_t levels) {
+    uint64_t g = 1;
+    for (uint32_t k = 1; k < levels; k++) g *= K;
+    if (levels > 1 && K == 0) return 1;
+    return std::max<uint64_t>(g, 1);
+}
+
+// Makes sure the wavefront buffers hold `n0` primary samples traced `levels` deep.
+int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
+    uint32_t K = c->max_bounce;
+    uint64_t node_cap = n0 * geo_sum(K, levels);
+    uint64_t q_cap = n0 * geo_last(K, levels);
+    uint32_t nl = std::max<uint32_t>(c->ds.n_lights, 1);
+    if (node_cap >= 0xFFFFFF00ull) {
+        c->err = "batch exceeds 2^32 path nodes";
+        return RTX_ERR_CAPACITY;
+    }
+    if (c->fr.ray_o && node_cap <= c->node_cap && q_cap <= c->q_cap && nl <= c->frame_lights) {
+        c->fr.node_cap = (uint32_t)c->node_cap;
+        c->fr.q_cap = (uint32_t)c->q_cap;
+        return RTX_OK;
+    }
+    free_all(c->frame_allocs);
+    c->fr = Frame{};
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
+        if (e == hipSuccess) c->frame_allocs.push_back(*p);
+        return e;
+    };
+    HIP_TRY(c, alloc((void **)&c->fr.ray_o, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&c->fr.ray_d, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&c->fr.link, node_cap * sizeof(uint2)));
+    HIP_TRY(c, alloc((void **)&c->fr.color, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&c->fr.shadow_q, (size_t)nl * q_cap * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&c->fr.counters, CTR_WORDS * sizeof(uint32_t)));
+    size_t threads = (size_t)c->persistent_blocks * 256;
+    HIP_TRY(c, alloc((void **)&c->fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t)));
+    c->node_cap = node_cap;
+    c->q_cap = q_cap;
+    c->cap0 = n0;
+    c->frame_lights = nl;
+    c->fr.node_cap = (uint32_t)node_cap;
+    c->fr.q_cap = (uint32_t)q_cap;
+    return RTX_OK;
+}
+
+int ensure_pixels(rtx_ctx *c, uint64_t npix, bool want_f32) {
+    if (npix > c->pix_cap || !c->sum) {
+        if (c->sum) (void)hipFree(c->sum);
+        if (c->tiles) (void)hipFree(c->tiles);
+        if (c->tiles_f32) (void)hipFree(c->tiles_f32);
+        c->sum = nullptr;
+        c->tiles = nullptr;
+        c->tiles_f32 = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->sum, std::max<size_t>(npix * sizeof(float4), 256)));
+        HIP_TRY(c, hipMalloc((void **)&c->tiles, std::max<size_t>(npix * 3, 256)));
+        c->pix_cap = npix;
+    }
+    if (want_f32 && !c->tiles_f32)
+        HIP_TRY(c, hipMalloc((void **)&c->tiles_f32, std::max<size_t>(c->pix_cap * 3 * sizeof(float), 256)));
+    return RTX_OK;
+}
+
+int ensure_counter_slots(rtx_ctx *c, uint32_t slots) {
+    if (slots <= c->h_counter_slots) return RTX_OK;
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    c->h_counters = nullptr;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, (size_t)slots * CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    c->h_counter_slots = slots;
+    return RTX_OK;
+}
+
+int ensure_events(rtx_ctx *c, size_t n) {
+    while (c->events.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->events.push_back(e);
+    }
+    return RTX_OK;
+}
+
+struct Batch {
+    uint32_t q0, npix, s0, ns;
+};
+
+// Runs the wavefront pipeline of one batch whose level-0 rays are already in the frame.
+// Records 4 events per level starting at events[ev0] when timing is on.
+void run_levels(rtx_ctx *c, const LaunchCfg &lc, uint32_t levels, bool timing, size_t ev0) {
+    for (uint32_t k = 0; k < levels; k++) {
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], lc.stream);
+        launch_trace_closest(c->ds, c->fr, k, lc);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], lc.stream);
+        launch_shade_forward(c->ds, c->fr, k, levels, lc);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], lc.stream);
+        launch_trace_shadow(c->ds, c->fr, k, lc);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], lc.stream);
+    }
+    for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, c->fr, (uint32_t)k, lc);
+    if (levels == 0) launch_resolve(c->ds, c->fr, 0, lc);
+}
+
+int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part, uint32_t flags,
+                void *d_tiles_out, bool want_f32, rtx_stats *stats, Partition &pt) {
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    if (spp == 0) {
+        c->err = "samples_per_pixel must be non-zero (world.rs:30)";
+        return RTX_ERR_INVALID;
+    }
+    if (bounces > 8) {
+        c->err = "max_ray_bounces > 8 not supported";
+        return RTX_ERR_CAPACITY;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = make_partition(c, part, pt);
+    if (rc != RTX_OK) return rc;
+    if (pt.npix >= 0xFFFFFFFFull) {
+        c->err = "more than 2^32 pixel slots per rank";
+        return RTX_ERR_CAPACITY;
+    }
+    uint32_t levels = bounces;
+    uint32_t K = c->max_bounce;
+    uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 56 + geo_last(K, std::max(levels, 1u)) * 4 * std::max(c->ds.n_lights, 1u);
+    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / per_sample, 4096);
+    uint64_t total = pt.npix * spp;
+    std::vector<Batch> batches;
+    if (total <= cap0) {
+        batches.push_back(Batch{0, (uint32_t)pt.npix, 0, spp});
+    } else if (pt.npix <= cap0) {
+        uint32_t nsc = (uint32_t)(cap0 / pt.npix);
+        for (uint32_t s0 = 0; s0 < spp; s0 += nsc) batches.push_back(Batch{0, (uint32_t)pt.npix, s0, std::min(nsc, spp - s0)});
+    } else {
+        uint64_t chunk = cap0 & ~63ull;
+        for (uint64_t q0 = 0; q0 < pt.npix; q0 += chunk)
+            for (uint32_t s0 = 0; s0 < spp; s0++)
+                batches.push_back(Batch{(uint32_t)q0, (uint32_t)std::min<uint64_t>(chunk, pt.npix - q0), s0, 1});
+    }
+    uint64_t n0max = 0;
+    for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
+    rc = ensure_frame(c, n0max, std::max(levels, 1u));
+    if (rc != RTX_OK) return rc;
+    rc = ensure_pixels(c, pt.npix, want_f32);
+    if (rc != RTX_OK) return rc;
+    rc = ensure_counter_slots(c, (uint32_t)batches.size());
+    if (rc != RTX_OK) return rc;
+    bool timing = stats != nullptr;
+    size_t ev_per_batch = 4 * (size_t)levels;
+    if (timing) {
+        rc = ensure_events(c, ev_per_batch * batches.size());
+        if (rc != RTX_OK) return rc;
+    }
+    LaunchCfg lc{c->stream, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
+                 (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    uint8_t *tiles = d_tiles_out ? static_cast<uint8_t *>(d_tiles_out) : c->tiles;
+    double t0 = 0;
+    if (timing) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        t0 = now_s();
+    }
+    for (size_t bi = 0; bi < batches.size(); bi++) {
+        const Batch &b = batches[bi];
+        BatchInfo info{};
+        info.q0 = b.q0;
+        info.npix = b.npix;
+        info.s0 = b.s0;
+        info.ns = b.ns;
+        info.spp = spp;
+        info.use_jitter = spp != 1;  // world.rs:47-51
+        info.seed_lo = (uint32_t)seed;
+        info.seed_hi = (uint32_t)(seed >> 32);
+        info.tile = pt.tile;
+        info.rank = pt.rank;
+        info.nranks = pt.nranks;
+        info.tiles_x = pt.tiles_x;
+        info.tiles_y = pt.tiles_y;
+        info.max_levels = levels;
+        HIP_TRY(c, hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream));
+        launch_raygen(c->ds, c->fr, info, lc);
+        run_levels(c, lc, levels, timing, ev_per_batch * bi);
+        launch_accumulate(c->ds, c->fr, info, c->sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
+        HIP_TRY(c, hipMemcpyAsync(c->h_counters + bi * CTR_WORDS, c->fr.counters, CTR_WORDS * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (!stats && d_tiles_out) return RTX_OK;  // asynchronous device render
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool overflow = false;
+    for (size_t bi = 0; bi < batches.size(); bi++)
+        if (c->h_counters[bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
+    if (overflow) {
+        c->err = "wavefront queue overflow (internal sizing error)";
+        return RTX_ERR_CAPACITY;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->trace_ms = (now_s() - t0) * 1e3;
+        stats->batches = (uint32_t)batches.size();
+        // valid primary samples of this rank
+        uint64_t valid = 0;
+        for (uint32_t lt = 0; lt < pt.my_tiles; lt++) {
+            uint64_t gt = (uint64_t)lt * pt.nranks + pt.rank;
+            uint32_t tx = (uint32_t)(gt % pt.tiles_x), ty = (uint32_t)(gt / pt.tiles_x);
+            uint32_t w = std::min(pt.tile, c->ds.width - std::min(c->ds.width, tx * pt.tile));
+            uint32_t h = std::min(pt.tile, c->ds.height - std::min(c->ds.height, ty * pt.tile));
+            valid += (uint64_t)w * h;
+        }
+        stats->primary_rays = levels ? valid * spp : 0;
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const uint32_t *h = c->h_counters + bi * CTR_WORDS;
+            for (uint32_t k = 1; k < 8; k++) stats->bounce_rays += h[CTR_LEVEL_COUNT + k];
+            for (uint32_t k = 0; k < 8 * (uint32_t)MAX_LIGHTS; k++) stats->shadow_rays += h[CTR_SHADOW_COUNT + k];
+            stats->nodes_visited += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
+            stats->prims_tested += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
+            for (uint32_t k = 0; k < levels; k++) {
+                float ms = 0;
+                size_t e = ev_per_batch * bi + 4 * k;
+                if (hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]) == hipSuccess) stats->closest_kernel_ms += ms;
+                if (hipEventElapsedTime(&ms, c->events[e + 2], c->events[e + 3]) == hipSuccess) stats->shadow_kernel_ms += ms;
+                stats->closest_launches++;
+                stats->shadow_launches++;
+            }
+        }
+    }
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_init(int device, rtx_ctx **out) {
+    if (!out) return RTX_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_init_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                       " (this backend has no CPU fallback)";
+        return RTX_ERR_HIP;
+    }
+    if (device < 0 || device >= n) {
+        g_init_error = "device index out of range";
+        return RTX_ERR_INVALID;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return RTX_ERR_HIP;
+    }
+    rtx_ctx *c = new rtx_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete c;
+        return RTX_ERR_HIP;
+    }
+    c->persistent_blocks = query_persistent_blocks(device);
+    if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
+        long v = std::atol(mb);
+        if (v > 0) c->node_budget_bytes = (uint64_t)v << 20;
+    }
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c->scene_allocs);
+    free_all(c->frame_allocs);
+    if (c->sum) (void)hipFree(c->sum);
+    if (c->tiles) (void)hipFree(c->tiles);
+    if (c->tiles_f32) (void)hipFree(c->tiles_f32);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto e : c->events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *rtx_last_error(rtx_ctx *c) { return c ? c->err.c_str() : g_init_error.c_str(); }
+
+int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
+    if (!c || !d) return RTX_ERR_INVALID;
+    if (d->width == 0 || d->height == 0) {
+        c->err = "camera width/height must be non-zero";
+        return RTX_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_all(c->scene_allocs);
+    c->has_scene = false;
+    c->info = rtx_bvh_info{};
+    int threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *t = std::getenv("RTX_BUILD_THREADS")) threads = std::max(1, std::atoi(t));
+    double t0 = now_s();
+    BuiltBvh bvh;
+    int rc = build_bvh(*d, threads, bvh, c->err);
+    if (rc != RTX_OK) return rc;
+    double t1 = now_s();
+    if (bvh.depth + 2 > (uint32_t)MAX_TREE_DEPTH) {
+        c->err = "BVH deeper than the traversal stack (120)";
+        return RTX_ERR_CAPACITY;
+    }
+    FlatScene fs;
+    rc = flatten_scene(*d, bvh, fs, c->err);
+    if (rc != RTX_OK) return rc;
+    double t2 = now_s();
+    DeviceScene &ds = c->ds;
+    ds = DeviceScene{};
+    if ((rc = upload(c, fs.nodes, &ds.nodes, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.prims, &ds.prims, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.xforms, &ds.xforms, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.mats, &ds.mats, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.prog, &ds.prog, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.tex, &ds.tex, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.tex_data, &ds.tex_data, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.lights, &ds.lights, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.prim_obj, &ds.prim_obj, c->scene_allocs))) return rc;
+    ds.n_prims = (uint32_t)fs.prims.size();
+    ds.n_lights = (uint32_t)fs.lights.size();
+    ds.root_ref = fs.root_ref;
+    float scale = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        ds.root_mn[k] = fs.root_mn[k];
+        ds.root_mx[k] = fs.root_mx[k];
+        scale = std::max(scale, std::max(std::fabs(fs.root_mn[k]), std::fabs(fs.root_mx[k])));
+        float bgc = d->background[k];
+        ds.background[k] = bgc < 0.0f ? 0.0f : (bgc > 1.0f ? 1.0f : bgc);
+    }
+    ds.coord_scale = scale;
+    std::memcpy(ds.c2w, d->camera_to_world, sizeof(ds.c2w));
+    ds.width = d->width;
+    ds.height = d->height;
+    double t3 = now_s();
+    c->leaf_order = std::move(bvh.leaf_order);
+    c->preorder_sizes = std::move(fs.preorder_sizes);
+    c->max_bounce = fs.max_bounce;
+    c->info.n_objects = d->n_objects;
+    c->info.n_internal = (uint32_t)fs.nodes.size();
+    c->info.n_leaves = fs.n_leaves;
+    c->info.depth = bvh.depth;
+    c->info.total_sa = fs.total_sa;
+    c->info.build_seconds = t1 - t0;
+    c->info.flatten_seconds = t2 - t1;
+    c->info.upload_seconds = t3 - t2;
+    c->has_scene = true;
+    return RTX_OK;
+}
+
+int rtx_bvh_info_get(rtx_ctx *c, rtx_bvh_info *out) {
+    if (!c || !out) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    *out = c->info;
+    return RTX_OK;
+}
+
+int rtx_bvh_digest(rtx_ctx *c, uint32_t *leaf_order, uint32_t *preorder_sizes) {
+    if (!c) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    if (leaf_order) std::copy(c->leaf_order.begin(), c->leaf_order.end(), leaf_order);
+    if (preorder_sizes) std::copy(c->preorder_sizes.begin(), c->preorder_sizes.end(), preorder_sizes);
+    return (int)c->preorder_sizes.size();
+}
+
+uint64_t rtx_partition_pixels(rtx_ctx *c, const rtx_partition *part) {
+    if (!c || !c->has_scene) return 0;
+    Partition pt;
+    if (make_partition(c, part, pt) != RTX_OK) return 0;
+    return pt.npix;
+}
+
+void *rtx_stream(rtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int rtx_synchronize(rtx_ctx *c) {
+    if (!c) return RTX_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_render_device(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
+                      uint32_t flags, void *d_tiles, rtx_stats *stats) {
+    if (!c || !d_tiles) return RTX_ERR_INVALID;
+    Partition pt;
+    return render_impl(c, spp, bounces, seed, part, flags, d_tiles, false, stats, pt);
+}
+
+int rtx_render(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part, uint32_t flags,
+               uint8_t *out_rgb8, float *out_f32, rtx_stats *stats) {
+    if (!c || !out_rgb8) return RTX_ERR_INVALID;
+    Partition pt;
+    rtx_stats local;
+    int rc = render_impl(c, spp, bounces, seed, part, flags, nullptr, out_f32 != nullptr, stats ? stats : &local, pt);
+    if (rc != RTX_OK) return rc;
+    std::vector<uint8_t> h8(pt.npix * 3);
+    HIP_TRY(c, hipMemcpy(h8.data(), c->tiles, h8.size(), hipMemcpyDeviceToHost));
+    std::vector<float> hf;
+    if (out_f32) {
+        hf.resize(pt.npix * 3);
+        HIP_TRY(c, hipMemcpy(hf.data(), c->tiles_f32, hf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    // tiles [local tile][row][col] -> row-major image
+    uint32_t T = pt.tile, W = c->ds.width, H = c->ds.height;
+    for (uint32_t lt = 0; lt < pt.my_tiles; lt++) {
+        uint64_t gt = (uint64_t)lt * pt.nranks + pt.rank;
+        uint32_t tx = (uint32_t)(gt % pt.tiles_x), ty = (uint32_t)(gt / pt.tiles_x);
+        for (uint32_t y = 0; y < T; y++) {
+            uint32_t py = ty * T + y;
+            if (py >= H) break;
+            uint32_t x0 = tx * T;
+            if (x0 >= W) break;
+            uint32_t w = std::min(T, W - x0);
+            size_t src = ((size_t)lt * T * T + (size_t)y * T) * 3;
+            size_t dst = ((size_t)py * W + x0) * 3;
+            std::memcpy(out_rgb8 + dst, h8.data() + src, (size_t)w * 3);
+            if (out_f32) std::memcpy(out_f32 + dst, hf.data() + src, (size_t)w * 3 * sizeof(float));
+        }
+    }
+    return RTX_OK;
+}
+
+int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed, uint32_t flags, uint32_t *out_obj,
+                      float *out_t) {
+    if (!c || !out_obj || !out_t) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    Partition pt;
+    int rc = make_partition(c, nullptr, pt);
+    if (rc != RTX_OK) return rc;
+    uint64_t chunk = std::min<uint64_t>(pt.npix, 1ull << 24);
+    rc = ensure_frame(c, chunk, 1);
+    if (rc != RTX_OK) return rc;
+    LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    uint32_t *d_obj = nullptr;
+    float *d_t = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_obj, chunk * 4));
+    HIP_TRY(c, hipMalloc((void **)&d_t, chunk * 4));
+    std::vector<uint32_t> h_obj(chunk);
+    std::vector<float> h_t(chunk);
+    int result = RTX_OK;
+    for (uint64_t q0 = 0; q0 < pt.npix && result == RTX_OK; q0 += chunk) {
+        uint32_t n = (uint32_t)std::min<uint64_t>(chunk, pt.npix - q0);
+        BatchInfo info{};
+        info.q0 = (uint32_t)q0;
+        info.npix = n;
+        info.s0 = sample;
+        info.ns = 1;
+        info.spp = 1;
+        info.use_jitter = use_jitter ? 1 : 0;
+        info.seed_lo = (uint32_t)seed;
+        info.seed_hi = (uint32_t)(seed >> 32);
+        info.tile = pt.tile;
+        info.rank = 0;
+        info.nranks = 1;
+        info.tiles_x = pt.tiles_x;
+        info.tiles_y = pt.tiles_y;
+        info.max_levels = 1;
+        (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
+        launch_raygen(c->ds, c->fr, info, lc);
+        launch_trace_closest(c->ds, c->fr, 0, lc);
+        launch_export_hits(c->ds, c->fr, n, d_obj, d_t, lc);
+        hipError_t e = hipMemcpyAsync(h_obj.data(), d_obj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_t.data(), d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->err = std::string("trace_primary: ") + hipGetErrorString(e);
+            result = RTX_ERR_HIP;
+            break;
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t px, py;
+            if (slot_to_pixel(pt, c->ds.width, c->ds.height, q0 + i, px, py)) {
+                out_obj[(size_t)py * c->ds.width + px] = h_obj[i];
+                out_t[(size_t)py * c->ds.width + px] = h_t[i];
+            }
+        }
+    }
+    (void)hipFree(d_obj);
+    (void)hipFree(d_t);
+    return result;
+}
+
+static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flags, uint32_t depth, uint32_t *out_obj,
+                     float *out_t, float *out_rgb) {
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    if (n == 0) return RTX_OK;
+    if (depth > 8) {
+        c->err = "depth > 8 not supported";
+        return RTX_ERR_CAPACITY;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t levels = out_rgb ? depth : 1;
+    uint64_t chunk = std::min<uint64_t>(n, 1ull << 22);
+    int rc = ensure_frame(c, chunk, std::max(levels, 1u));
+    if (rc != RTX_OK) return rc;
+    LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    float *d_rays = nullptr, *d_f = nullptr;
+    uint32_t *d_obj = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_rays, chunk * 24));
+    HIP_TRY(c, hipMalloc((void **)&d_f, chunk * 12));
+    HIP_TRY(c, hipMalloc((void **)&d_obj, chunk * 4));
+    int result = RTX_OK;
+    for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
+        uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - i0);
+        hipError_t e = hipMemcpyAsync(d_rays, org_dir + i0 * 6, (size_t)m * 24, hipMemcpyHostToDevice, c->stream);
+        (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
+        launch_load_rays(c->fr, d_rays, m, lc);
+        if (out_rgb) {
+            run_levels(c, lc, levels, false, 0);
+            launch_export_colors(c->fr, m, d_f, lc);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
+        } else {
+            launch_trace_closest(c->ds, c->fr, 0, lc);
+            launch_export_hits(c->ds, c->fr, m, d_obj, d_f, lc);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_obj + i0, d_obj, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_t + i0, d_f, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->err = std::string("trace rays: ") + hipGetErrorString(e);
+            result = RTX_ERR_HIP;
+            break;
+        }
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_f);
+    (void)hipFree(d_obj);
+    return result;
+}
+
+int rtx_trace_rays(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flags, uint32_t *out_obj, float *out_t) {
+    if (!c || (n && (!org_dir || !out_obj || !out_t))) return RTX_ERR_INVALID;
+    return rays_impl(c, org_dir, n, flags, 1, out_obj, out_t, nullptr);
+}
+
+int rtx_shade_rays(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t depth, float *out_rgb) {
+    if (!c || (n && (!org_dir || !out_rgb))) return RTX_ERR_INVALID;
+    return rays_impl(c, org_dir, n, 0, depth, nullptr, nullptr, out_rgb);
+}
+
+int rtx_host_bvh_digest(const rtx_scene_desc *d, int threads, uint32_t *leaf_order, uint32_t *preorder_sizes,
+                        uint32_t *depth, float *total_sa, uint32_t *n_internal) {
+    if (!d) return RTX_ERR_INVALID;
+    BuiltBvh bvh;
+    std::string err;
+    int rc = build_bvh(*d, threads, bvh, err);
+    if (rc != RTX_OK) {
+        g_init_error = err;
+        return rc;
+    }
+    FlatScene fs;
+    rc = flatten_scene(*d, bvh, fs, err);
+    if (rc != RTX_OK) {
+        g_init_error = err;
+        return rc;
+    }
+    if (leaf_order) std::copy(bvh.leaf_order.begin(), bvh.leaf_order.end(), leaf_order);
+    if (preorder_sizes) std::copy(fs.preorder_sizes.begin(), fs.preorder_sizes.end(), preorder_sizes);
+    if (depth) *depth = bvh.depth;
+    if (total_sa) *total_sa = fs.total_sa;
+    if (n_internal) *n_internal = (uint32_t)fs.nodes.size();
+    return (int)fs.preorder_sizes.size();
+}
+
+}  // extern "C"
