@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s on the 2.37 M-triangle scene, 1024^2, 16 spp, 4 bounces.
+
+One "step" = one full pass of the trace path (raygen -> closest/shadow traversal -> shading
+-> resolve -> RGB8 tiles) over the frame, scene already resident in HBM.  With N > 1 ranks
+(one process per GPU, torch.distributed over RCCL) the frame is split into interleaved
+32x32 tiles, every rank traces its tiles against its own copy of the scene, and the
+finished RGB8 tiles are all-gathered; total work is fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints one JSON line on rank 0 (see DESIGN.md for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RAY_IO_BYTES = 40      # 32 B ray in + 8 B hit out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="scan")
+    ap.add_argument("--tris", type=int, default=0, help="triangle count of the synthetic scene (0 = 2,374,525)")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=2, help="oracle traces every n-th image row")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    rt = importlib.import_module("rust-raytracer_amd")
+    ctx = rt.Context(local_rank)
+    t0 = time.time()
+    scene = rt.HostScene(args.scene, args.width, args.tris)
+    t_scene = time.time() - t0
+    info = ctx.upload(scene)
+    part = (args.tile, rank, world)
+    npix = ctx.partition_pixels(part)
+    tiles = torch.zeros(npix * 3, dtype=torch.uint8, device=device)
+    gathered = torch.zeros(world * npix * 3, dtype=torch.uint8, device=device) if world > 1 else None
+
+    def step(flags=0):
+        st = ctx.render_device(tiles.data_ptr(), args.spp, args.bounces, seed=1, part=part, flags=flags)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, tiles)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    counted = step(rt.FLAG_COUNT_VISITS)  # untimed pass with visit counters on
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    rays_step = stats[-1].rays
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rays_step], dtype=torch.int64, device=device)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays_step = int(rr.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_step * args.steps / elapsed / 1e6
+    # dominant kernel of rank 0 (HIP events recorded on the library's stream around each launch)
+    c_ms = sum(s.closest_kernel_ms for s in stats)
+    s_ms = sum(s.shadow_kernel_ms for s in stats)
+    c_l = sum(s.closest_launches for s in stats)
+    s_l = sum(s.shadow_launches for s in stats)
+    c_rays = counted.primary_rays + counted.bounce_rays
+    s_rays = counted.shadow_rays
+    c_bytes = 64 * (counted.closest_nodes + counted.closest_prims) + RAY_IO_BYTES * c_rays
+    s_bytes = 64 * (counted.shadow_nodes + counted.shadow_prims) + RAY_IO_BYTES * s_rays
+    if s_ms >= c_ms:
+        kname, k_ms, k_l, k_bytes, k_rays = "trace_shadow", s_ms, s_l, s_bytes, s_rays
+    else:
+        kname, k_ms, k_l, k_bytes, k_rays = "trace_closest", c_ms, c_l, c_bytes, c_rays
+    launches_per_step = k_l / args.steps
+    avg_launch_ms = k_ms / max(k_l, 1)
+    achieved = (k_bytes / max(launches_per_step, 1)) / (avg_launch_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_step": int(k_bytes), "rays_per_step": int(k_rays),
+                "bytes_per_ray": round(k_bytes / max(k_rays, 1), 1),
+                "visits_per_step": {"closest_nodes": int(counted.closest_nodes), "closest_prims": int(counted.closest_prims),
+                                    "shadow_nodes": int(counted.shadow_nodes), "shadow_prims": int(counted.shadow_prims)},
+                "other_kernel": {"name": "trace_closest" if kname == "trace_shadow" else "trace_shadow",
+                                 "ms_per_step": round((c_ms if kname == "trace_shadow" else s_ms) / args.steps, 4),
+                                 "GB/s": round((c_bytes if kname == "trace_shadow" else s_bytes) /
+                                               max((c_ms if kname == "trace_shadow" else s_ms) / args.steps * 1e-3, 1e-12) / 1e9, 2)}}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc  # the oracle, as the reported CPU baseline only
+        threads = min(16, os.cpu_count() or 1)
+        o = orc.Scene(scene)
+        ys = max(1, args.cpu_row_stride)
+        _, cst = o.render(spp=args.spp, bounces=args.bounces, seed=1, threads=threads,
+                          region=(0, args.width, 1, 0, args.width, ys))
+        cpu = {"value": round(cst.rays / cst.trace_seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"every {ys}. row of the same {args.width}x{args.width} {args.spp}-spp frame "
+                         f"({cst.rays} rays in {cst.trace_seconds:.1f} s; oracle BVH build {cst.build_seconds:.1f} s extra)"}
+        o.close()
+
+    out = {"metric": "Mrays/s at 2.3M-tri 1024^2 16spp", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.scene}: load_basic + 4 synthetic scan-like meshes, {info.n_objects} primitives, "
+                                  f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
+                      "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
+                      "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
+                      "bvh": {"internal_nodes": info.n_internal, "leaves": info.n_leaves, "depth": info.depth,
+                              "build_s": round(info.build_seconds, 3), "flatten_s": round(info.flatten_seconds, 3),
+                              "upload_s": round(info.upload_seconds, 3), "scene_gen_s": round(t_scene, 3),
+                              "device_MB": round(info.device_bytes / 2**20, 1)}},
+           "mprimary_samples_per_s": round(args.width * args.width * args.spp * args.steps / elapsed / 1e6, 2),
+           "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,8 +86,9 @@ typedef struct rtx_ctx rtx_ctx;
  * reference (world.rs:118, light.rs:90,111). */
 typedef struct rtx_stats {
     uint64_t primary_rays, bounce_rays, shadow_rays;
-    uint64_t nodes_visited;     /* internal BVH nodes fetched (64 B each); 0 unless counting is on */
-    uint64_t prims_tested;      /* primitive records fetched (64 B each); 0 unless counting is on */
+    /* 64-byte records fetched, per kernel class; 0 unless RTX_FLAG_COUNT_VISITS is set */
+    uint64_t closest_nodes, closest_prims;  /* trace_closest: internal nodes, primitive records */
+    uint64_t shadow_nodes, shadow_prims;    /* trace_shadow */
     double trace_ms;            /* host wall time raygen..resolve (stream-synchronised) */
     double closest_kernel_ms;   /* HIP-event time summed over trace_closest launches */
     double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches */

@@ -538,8 +538,8 @@ void add_scan_scene(SceneArrays &s, const std::string &media, uint64_t total, bo
         mats[3] = Material::make(MaterialType::Composition({{MaterialType::Reflective(), 0.5f}, {MaterialType::new_phong(0.5f, 0.5f, 6.0f), 0.5f}}),
                                  TextureType::new_flat(Color::rgb(0.9f, 0.75f, 0.3f)));
     }
-    const V3 centers[4] = {v3(-0.3f, -0.35f, 0.6f), v3(2.4f, -0.55f, 0.4f), v3(-2.9f, -0.3f, 0.2f), v3(0.2f, 0.1f, -3.6f)};
-    const float radii[4] = {0.55f, 0.38f, 0.6f, 0.9f};
+    const V3 centers[4] = {v3(-0.9f, -0.45f, 0.3f), v3(0.0f, -0.68f, 1.6f), v3(2.5f, -0.5f, 0.2f), v3(-0.5f, -0.3f, -1.3f)};
+    const float radii[4] = {0.55f, 0.3f, 0.45f, 0.65f};
     M4 id = m4_identity();
     int xf = s.add_xform(id, id);
     reserve_tris(s, total);

@@ -32,12 +32,17 @@ enum {
     CTR_LEVEL_COUNT = 0,    // [8]  path nodes per bounce level
     CTR_SHADOW_COUNT = 8,   // [8][MAX_LIGHTS] shadow-queue entries per level and light
     CTR_OVERFLOW = 8 + 8 * MAX_LIGHTS,
-    CTR_VISIT_NODES_LO = CTR_OVERFLOW + 1,  // 64-bit visit counters as lo/hi pairs
+    CTR_VISIT_NODES_LO = CTR_OVERFLOW + 2,  // trace_closest: 64-bit counters as lo/hi pairs (8-byte aligned)
     CTR_VISIT_NODES_HI,
     CTR_VISIT_PRIMS_LO,
     CTR_VISIT_PRIMS_HI,
+    CTR_SVISIT_NODES_LO,                    // trace_shadow
+    CTR_SVISIT_NODES_HI,
+    CTR_SVISIT_PRIMS_LO,
+    CTR_SVISIT_PRIMS_HI,
     CTR_WORDS = 160
 };
+static_assert(CTR_VISIT_NODES_LO % 2 == 0 && CTR_SVISIT_PRIMS_HI < CTR_WORDS, "64-bit counters must be 8-byte aligned");
 
 // Wavefront state of one batch of primary samples ("path nodes": one per traced ray).
 struct Frame {

@@ -90,35 +90,6 @@ __device__ __forceinline__ uint32_t jitter_u32(uint32_t seed_lo, uint32_t seed_h
 // ---------------------------------------------------------------- wave-level queue allocation
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// One slot per lane with pred set: ballot + popcount prefix, one atomic per wave.
-__device__ __forceinline__ uint32_t wave_alloc1(uint32_t *counter, bool pred) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return 0;
-    uint32_t lane = lane_id();
-    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    return base + prefix;
-}
-// n slots per lane (n small): shuffle prefix sum across the wave, one atomic per wave.
-__device__ __forceinline__ uint32_t wave_allocn(uint32_t *counter, uint32_t n) {
-    uint32_t lane = lane_id();
-    uint32_t incl = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += up;
-    }
-    uint32_t total = __shfl(incl, 63, 64);
-    if (total == 0) return 0;
-    uint32_t base = 0;
-    if (lane == 63) base = atomicAdd(counter, total);
-    base = __shfl(base, 63, 64);
-    return base + incl - n;
-}
-
 __device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t level) {
     uint32_t b = 0;
     for (uint32_t j = 0; j < level; j++) b += ctr[CTR_LEVEL_COUNT + j];
@@ -394,15 +365,15 @@ __device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, uint3
     }
 }
 
-__device__ __forceinline__ void add_visits(uint32_t *ctr, uint32_t nodes, uint32_t prims) {
+__device__ __forceinline__ void add_visits(uint32_t *ctr, uint32_t nodes, uint32_t prims, int first) {
     // wave reduction, then one 64-bit atomic pair per wave
     for (int d = 32; d > 0; d >>= 1) {
         nodes += __shfl_down(nodes, d, 64);
         prims += __shfl_down(prims, d, 64);
     }
     if (lane_id() == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + CTR_VISIT_NODES_LO), (unsigned long long)nodes);
-        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + CTR_VISIT_PRIMS_LO), (unsigned long long)prims);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + first), (unsigned long long)nodes);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ctr + first + 2), (unsigned long long)prims);
     }
 }
 
@@ -489,7 +460,7 @@ __global__ void __launch_bounds__(BLOCK) trace_closest_kernel(DeviceScene sc, Fr
             vp += out.prims;
         }
     }
-    if (COUNT) add_visits(fr.counters, vn, vp);
+    if (COUNT) add_visits(fr.counters, vn, vp, CTR_VISIT_NODES_LO);
 }
 
 // ---------------------------------------------------------------- object.rs helpers for shading
@@ -543,74 +514,151 @@ __device__ __forceinline__ void object_uv(const PrimView &v, const Xform *xforms
 // For every hit of this level: the shadow queries of world.rs:121-125 are queued per light
 // (cone pre-test of light.rs:113-116 applied here), and the bounce rays of
 // material.rs:185-203 are appended to the next level's queue.
+//
+// Queue compaction: a block takes SF_R*256 consecutive path nodes; every wave ranks its
+// lanes with ballot + popcount (shadow queues) or a shuffle prefix sum (bounce children),
+// the four wave totals are combined in LDS, and ONE atomic per queue per block reserves
+// the block's range -- a single hot counter sustains only ~90 atomics/us on MI355X, so a
+// per-wave atomic would cost more than the traversal it feeds.
+constexpr int SF_R = 4;
+constexpr int SF_Q = MAX_LIGHTS + 1;  // queues: one per light + the next level's nodes
+
 __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Frame fr, uint32_t level,
                                                               uint32_t max_levels) {
+    __shared__ uint32_t s_tot[BLOCK / 64][SF_Q];  // per-wave totals, then per-wave offsets
+    __shared__ uint32_t s_base[SF_Q];
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
     const uint32_t next_base = base + count;
-    const uint32_t nthreads = gridDim.x * BLOCK;
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
-        uint32_t i = i0 + threadIdx.x;
-        bool active = i < count;
-        uint32_t node = base + (active ? i : 0);
-        float4 o4 = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 0, 0);
-        uint32_t prim = NO_PRIM;
-        if (active) {
-            o4 = fr.ray_o[node];
-            d4 = fr.ray_d[node];
-            prim = __float_as_uint(d4.w);
-        }
-        bool hit = active && prim < INVALID_PRIM;
-        F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
-        F3 p = o + o4.w * d;  // ray.get_point_on_ray(t) (world.rs:120)
-        uint32_t lit = 0;
-        for (uint32_t l = 0; l < sc.n_lights; l++) {
-            const LightRec &L = sc.lights[l];
-            bool want = false;
-            if (hit) {
-                if (L.type == LIGHT_AMBIENT) lit |= 1u << l;
-                else if (L.type == 3u) {
-                    F3 ld = p - f3(L.pos[0], L.pos[1], L.pos[2]);
-                    want = !(angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), ld) > L.angle_deg * DEG_TO_RAD);
-                } else want = true;
-            }
-            uint32_t slot = wave_alloc1(fr.counters + CTR_SHADOW_COUNT + level * MAX_LIGHTS + l, want);
-            if (want) {
-                if (slot < fr.q_cap) fr.shadow_q[(size_t)l * fr.q_cap + slot] = node;
-                else fr.counters[CTR_OVERFLOW] = 1;
-            }
-        }
-        uint32_t nb = 0;
-        PrimView pv;
-        MaterialRec m;
-        if (hit) {
-            pv = load_prim(sc.prims + prim);
-            m = sc.mats[pv.mat];
-            if (level + 1 < max_levels) nb = m.n_bounce;
-        }
-        uint32_t off = wave_allocn(fr.counters + CTR_LEVEL_COUNT + level + 1, nb);
-        uint32_t child = NO_PRIM;
-        if (nb) {
-            if (next_base + off + nb <= fr.node_cap) {
-                child = next_base + off;
-                F3 normal = object_normal(pv, sc.xforms, p);
-                for (uint32_t k = 0; k < m.prog_count; k++) {
-                    const MatInstr &ins = sc.prog[m.prog_first + k];
-                    if (ins.op != OP_REFLECT && ins.op != OP_REFRACT) continue;
-                    F3 nd = (ins.op == OP_REFLECT) ? reflect(d, normal) : refract(d, normal, ins.p0);
-                    // Ray::new(p, nd).offset(1e-4) (material.rs:189-191, ray.rs:43-46)
-                    F3 rd = normalize(nd);
-                    F3 ro = p + 1e-4f * rd;
-                    rd = normalize(rd);
-                    uint32_t cn = child + ins.arg;
-                    fr.ray_o[cn] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-                    fr.ray_d[cn] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(NO_PRIM));
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t nl = sc.n_lights;
+    for (uint32_t i0 = blockIdx.x * (BLOCK * SF_R); i0 < count; i0 += gridDim.x * (BLOCK * SF_R)) {
+        // ---- phase 1: what does every node need?
+        uint32_t want[SF_R], nb[SF_R], lit[SF_R];
+#pragma unroll
+        for (int r = 0; r < SF_R; r++) {
+            uint32_t i = i0 + r * BLOCK + threadIdx.x;
+            want[r] = 0;
+            nb[r] = 0;
+            lit[r] = 0;
+            if (i < count) {
+                uint32_t node = base + i;
+                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                uint32_t prim = __float_as_uint(d4.w);
+                if (prim < INVALID_PRIM) {
+                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);  // world.rs:120
+                    for (uint32_t l = 0; l < nl; l++) {
+                        const LightRec &L = sc.lights[l];
+                        if (L.type == LIGHT_AMBIENT) lit[r] |= 1u << l;
+                        else if (L.type == LIGHT_CONE) {
+                            F3 ld = p - f3(L.pos[0], L.pos[1], L.pos[2]);
+                            if (!(angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), ld) > L.angle_deg * DEG_TO_RAD))
+                                want[r] |= 1u << l;
+                        } else want[r] |= 1u << l;
+                    }
+                    if (level + 1 < max_levels) {
+                        uint32_t meta = sc.prims[prim].meta;
+                        nb[r] = sc.mats[meta >> 16].n_bounce;
+                    }
                 }
-            } else {
-                fr.counters[CTR_OVERFLOW] = 1;
             }
         }
-        if (active) fr.link[node] = make_uint2(lit, child);
+        // ---- wave totals -> LDS -> one atomic per queue per block
+        for (uint32_t l = 0; l < nl; l++) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int r = 0; r < SF_R; r++) tot += (uint32_t)__popcll(__ballot((want[r] >> l) & 1u));
+            if (lane == 0) s_tot[wave][l] = tot;
+        }
+        uint32_t child_off[SF_R];
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int r = 0; r < SF_R; r++) {
+                uint32_t incl = nb[r];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t up = __shfl_up(incl, d, 64);
+                    if (lane >= (uint32_t)d) incl += up;
+                }
+                child_off[r] = run + incl - nb[r];
+                run += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) s_tot[wave][MAX_LIGHTS] = run;
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)SF_Q) {
+            uint32_t q = threadIdx.x;
+            bool used = q < nl || q == (uint32_t)MAX_LIGHTS;
+            uint32_t sum = 0;
+            if (used) {
+                for (int w = 0; w < BLOCK / 64; w++) {
+                    uint32_t t = s_tot[w][q];
+                    s_tot[w][q] = sum;
+                    sum += t;
+                }
+            }
+            uint32_t b = 0;
+            if (used && sum) {
+                uint32_t *ctr = q == (uint32_t)MAX_LIGHTS ? fr.counters + CTR_LEVEL_COUNT + level + 1
+                                                          : fr.counters + CTR_SHADOW_COUNT + level * MAX_LIGHTS + q;
+                b = atomicAdd(ctr, sum);
+            }
+            s_base[q] = b;
+        }
+        __syncthreads();
+        // ---- phase 2: write the queue entries, the bounce rays and the node links
+        for (uint32_t l = 0; l < nl; l++) {
+            uint32_t run = s_base[l] + s_tot[wave][l];
+#pragma unroll
+            for (int r = 0; r < SF_R; r++) {
+                bool mine = (want[r] >> l) & 1u;
+                unsigned long long mask = __ballot(mine);
+                if (mine) {
+                    uint32_t slot = run + (uint32_t)__popcll(mask & lt_mask);
+                    if (slot < fr.q_cap) fr.shadow_q[(size_t)l * fr.q_cap + slot] = base + i0 + r * BLOCK + threadIdx.x;
+                    else fr.counters[CTR_OVERFLOW] = 1;
+                }
+                run += (uint32_t)__popcll(mask);
+            }
+        }
+        const uint32_t child_base = next_base + s_base[MAX_LIGHTS] + s_tot[wave][MAX_LIGHTS];
+#pragma unroll
+        for (int r = 0; r < SF_R; r++) {
+            uint32_t i = i0 + r * BLOCK + threadIdx.x;
+            if (i >= count) continue;
+            uint32_t node = base + i;
+            uint32_t child = NO_PRIM;
+            if (nb[r]) {
+                uint32_t first = child_base + child_off[r];
+                if (first + nb[r] <= fr.node_cap) {
+                    child = first;
+                    float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                    F3 d = f3(d4.x, d4.y, d4.z);
+                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * d;
+                    PrimView pv = load_prim(sc.prims + __float_as_uint(d4.w));
+                    MaterialRec m = sc.mats[pv.mat];
+                    F3 normal = object_normal(pv, sc.xforms, p);
+                    for (uint32_t k = 0; k < m.prog_count; k++) {
+                        const MatInstr &ins = sc.prog[m.prog_first + k];
+                        if (ins.op != OP_REFLECT && ins.op != OP_REFRACT) continue;
+                        F3 nd = (ins.op == OP_REFLECT) ? reflect(d, normal) : refract(d, normal, ins.p0);
+                        // Ray::new(p, nd).offset(1e-4) (material.rs:189-191, ray.rs:43-46)
+                        F3 rd = normalize(nd);
+                        F3 ro = p + 1e-4f * rd;
+                        rd = normalize(rd);
+                        uint32_t cn = child + ins.arg;
+                        fr.ray_o[cn] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                        fr.ray_d[cn] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(NO_PRIM));
+                    }
+                } else {
+                    fr.counters[CTR_OVERFLOW] = 1;
+                }
+            }
+            fr.link[node] = make_uint2(lit[r], child);
+        }
+        __syncthreads();  // s_tot / s_base are reused by the next iteration
     }
 }
 
@@ -664,7 +712,7 @@ __global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Fra
             }
         }
     }
-    if (COUNT) add_visits(fr.counters, vn, vp);
+    if (COUNT) add_visits(fr.counters, vn, vp, CTR_SVISIT_NODES_LO);
 }
 
 // ---------------------------------------------------------------- resolve

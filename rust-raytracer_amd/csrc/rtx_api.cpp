@@ -337,8 +337,10 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             const uint32_t *h = c->h_counters + bi * CTR_WORDS;
             for (uint32_t k = 1; k < 8; k++) stats->bounce_rays += h[CTR_LEVEL_COUNT + k];
             for (uint32_t k = 0; k < 8 * (uint32_t)MAX_LIGHTS; k++) stats->shadow_rays += h[CTR_SHADOW_COUNT + k];
-            stats->nodes_visited += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
-            stats->prims_tested += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
+            stats->closest_nodes += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
+            stats->closest_prims += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
+            stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
+            stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
             for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
                 size_t e = ev_per_batch * bi + 4 * k;

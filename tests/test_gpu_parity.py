@@ -64,6 +64,19 @@ def test_image_matches_oracle(rt, orc, gpu, name, width, param, spp):
     assert abs(int(st_g.shadow_rays) - int(st_o.shadow_rays)) <= max(4, st_o.shadow_rays // 10000)
 
 
+def test_visit_counters(rt, gpu):
+    """RTX_FLAG_COUNT_VISITS: same image, non-zero counters; reference traversal visits more."""
+    s = rt.HostScene("basic_suzanne", 64)
+    gpu.upload(s)
+    img0, st0 = gpu.render(spp=2, bounces=4, seed=3)
+    img1, st1 = gpu.render(spp=2, bounces=4, seed=3, flags=rt.FLAG_COUNT_VISITS)
+    img2, st2 = gpu.render(spp=2, bounces=4, seed=3, flags=rt.FLAG_COUNT_VISITS | rt.FLAG_REFERENCE_TRAVERSAL)
+    assert np.array_equal(img0, img1) and np.array_equal(img0, img2)
+    assert st0.closest_nodes == 0 and st1.closest_nodes > 0 and st1.shadow_nodes > 0 and st1.closest_prims > 0
+    assert st2.closest_nodes > st1.closest_nodes and st2.shadow_nodes > st1.shadow_nodes
+    assert st1.rays == st0.rays == st2.rays
+
+
 def test_bounce_depths(rt, orc, gpu):
     s, o = _pair(rt, orc, gpu, "basic", 64, 0)
     for b in (0, 1, 2, 6):
