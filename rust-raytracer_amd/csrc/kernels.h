@@ -40,7 +40,9 @@ enum {
     CTR_SVISIT_NODES_HI,
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
-    CTR_WORDS = 160
+    CTR_WORK = 160,         // [8][CTR_WORK_STRIDE] queue heads of the persistent trace kernels:
+    CTR_WORK_STRIDE = 1 + MAX_LIGHTS,  //   word 0 = trace_closest, 1 + l = trace_shadow of light l
+    CTR_WORDS = CTR_WORK + 8 * CTR_WORK_STRIDE
 };
 static_assert(CTR_VISIT_NODES_LO % 2 == 0 && CTR_SVISIT_PRIMS_HI < CTR_WORDS, "64-bit counters must be 8-byte aligned");
 

@@ -90,6 +90,13 @@ __device__ __forceinline__ uint32_t jitter_u32(uint32_t seed_lo, uint32_t seed_h
 // ---------------------------------------------------------------- wave-level queue allocation
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// Queue head of a persistent kernel: lane 0 takes `n` work items, the wave shares the base.
+__device__ __forceinline__ uint32_t wave_fetch(uint32_t *head, uint32_t n) {
+    uint32_t b = 0;
+    if (lane_id() == 0) b = atomicAdd(head, n);
+    return __builtin_amdgcn_readfirstlane(b);
+}
+
 __device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t level) {
     uint32_t b = 0;
     for (uint32_t j = 0; j < level; j++) b += ctr[CTR_LEVEL_COUNT + j];
@@ -443,8 +450,12 @@ __global__ void __launch_bounds__(BLOCK) trace_closest_kernel(DeviceScene sc, Fr
     uint32_t *lds = lds_stack + threadIdx.x;
     uint32_t *spill = fr.spill + gtid;
     uint32_t vn = 0, vp = 0;
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
-        uint32_t i = i0 + threadIdx.x;
+    uint32_t *work = fr.counters + CTR_WORK + level * CTR_WORK_STRIDE;
+    for (;;) {
+        // persistent threads: every wave pulls its next 64 rays from the queue head
+        uint32_t i0 = wave_fetch(work, 64u);
+        if (i0 >= count) break;
+        uint32_t i = i0 + lane_id();
         if (i >= count) continue;
         uint32_t node = base + i;
         float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
@@ -679,8 +690,11 @@ __global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Fra
         const uint32_t *q = fr.shadow_q + (size_t)l * fr.q_cap;
         F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
         F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
-        for (uint32_t i0 = blockIdx.x * BLOCK; i0 < count; i0 += nthreads) {
-            uint32_t i = i0 + threadIdx.x;
+        uint32_t *work = fr.counters + CTR_WORK + level * CTR_WORK_STRIDE + 1 + l;
+        for (;;) {
+            uint32_t i0 = wave_fetch(work, 64u);
+            if (i0 >= count) break;
+            uint32_t i = i0 + lane_id();
             if (i >= count) continue;
             uint32_t node = q[i];
             float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
