@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
     ap.add_argument("--cpu-row-stride", type=int, default=2, help="oracle traces every n-th image row")
     args = ap.parse_args()
 
@@ -61,14 +62,16 @@ def main():
     t_scene = time.time() - t0
     info = ctx.upload(scene)
     part = (args.tile, rank, world)
-    npix = ctx.partition_pixels(part)
-    tiles = torch.zeros(npix * 3, dtype=torch.uint8, device=device)
-    gathered = torch.zeros(world * npix * 3, dtype=torch.uint8, device=device) if world > 1 else None
+    tl = importlib.import_module("rust-raytracer_amd.tiles")
+    n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
+    assert ctx.partition_pixels(part) <= n_pad * args.tile * args.tile
+    tiles = torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device)
+    frame = [None]
 
     def step(flags=0):
         st = ctx.render_device(tiles.data_ptr(), args.spp, args.bounces, seed=1, part=part, flags=flags)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tiles)
+        if world > 1:  # the frame's one exchange step: RGB8 tiles over RCCL, then de-interleave
+            frame[0] = tl.gather_image(tiles, args.width, args.width, args.tile, rank, world, dist)
         return st
 
     def fence():
@@ -98,6 +101,9 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.out:
+        img = frame[0] if world > 1 else tl.gather_image(tiles, args.width, args.width, args.tile, 0, 1)
+        rt.png_write(args.out, img.cpu().numpy())
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_step * args.steps / elapsed / 1e6
     # dominant kernel of rank 0 (HIP events recorded on the library's stream around each launch)

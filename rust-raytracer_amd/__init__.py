@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "librtx_hip.so")
 REPO_ROOT = os.path.dirname(_HERE)
 MEDIA_DIR = os.path.join(REPO_ROOT, "assets")
 

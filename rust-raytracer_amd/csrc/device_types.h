@@ -82,7 +82,10 @@ enum : uint32_t { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTIONAL = 2, LIG
 constexpr int MAX_LIGHTS = 16;
 constexpr int MAX_BOUNCE_LEAVES = 4;   // bounce leaves per material
 constexpr int MAX_COMP_DEPTH = 4;      // nesting of Composition
-constexpr int LDS_STACK = 24;          // per-lane traversal stack entries kept in LDS
+#ifndef RTX_LDS_STACK
+#define RTX_LDS_STACK 16
+#endif
+constexpr int LDS_STACK = RTX_LDS_STACK;          // per-lane traversal stack entries kept in LDS
 constexpr int MAX_TREE_DEPTH = 120;    // LDS_STACK + global spill entries per lane
 
 }  // namespace rtx

@@ -122,11 +122,11 @@ inline bool m4_invert(const M4 &M, M4 &out) {
         }
         return det3(cols[0][0], cols[0][1], cols[0][2], cols[1][0], cols[1][1], cols[1][2], cols[2][0], cols[2][1], cols[2][2]);
     };
-    // determinant by expansion along the first column of M
+    // determinant by expansion along the first row of M: sum_j (-1)^j M[0][j] * minor(0, j)
     float det = 0.0f;
     {
         float d0 = cof3(0, 0), d1 = cof3(0, 1), d2 = cof3(0, 2), d3 = cof3(0, 3);
-        det = M.at(0, 0) * d0 - M.at(0, 1) * d1 + M.at(0, 2) * d2 - M.at(0, 3) * d3;
+        det = M.at(0, 0) * d0 - M.at(1, 0) * d1 + M.at(2, 0) * d2 - M.at(3, 0) * d3;
     }
     if (det == 0.0f) return false;
     float inv_det = 1.0f / det;

@@ -17,6 +17,12 @@ namespace rtx {
 namespace {
 
 constexpr int BLOCK = 256;
+#ifndef RTX_WHILE_WHILE
+#define RTX_WHILE_WHILE 0
+#endif
+#ifndef RTX_TRACE_WAVES
+#define RTX_TRACE_WAVES 4  // waves per SIMD the trace kernels are register-allocated for
+#endif
 
 // ---------------------------------------------------------------- cgmath-order arithmetic
 struct F3 {
@@ -179,13 +185,20 @@ __device__ __noinline__ bool box_exact(float mnx, float mny, float mnz, float mx
     return true;
 }
 
-// Box decision + pruning.  The fast path multiplies by the reciprocal; its result can
-// differ from the division by < 2^-22 relative, so only clearly separated intervals are
-// decided there and the rest re-run the reference's divisions.  Pruning (behind the
-// origin / beyond the best hit) keeps a slack far above the f32 error of t.
-template <bool REF>
+// Box decision + pruning.
+//
+// Exactness argument: the reference tests a primitive iff its leaf box and every ancestor
+// box pass AABB::intersect.  A parent box is the min/max union of its children, and the
+// slab arithmetic ((a-x)/slope, min, max) is monotone under correct rounding, so a ray that
+// passes a box passes every ancestor of it: only the LEAF box decision can change a result.
+// Internal boxes are therefore tested conservatively (reciprocal multiply, accept unless
+// clearly separated); leaf boxes are decided exactly: the fast path settles clearly
+// separated intervals (the reciprocal form is within 2^-22 relative of the division) and
+// everything else re-runs the reference's divisions.  Pruning (box behind the origin or
+// beyond the best hit) keeps a slack far above the f32 error of t.
+// kind: 0 = internal child (conservative), 1 = leaf child / root (exact), 2 = exact, no pruning.
 __device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                         const RayCtx &r, float limit_plus, float &t_entry) {
+                                         const RayCtx &r, float limit_plus, bool exact, bool prune, float &t_entry) {
     float tmin, tmax;
     bool hit;
     if (!r.exact_only) {
@@ -195,14 +208,15 @@ __device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float 
         tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
         tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
         float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
-        if (tmin <= tmax - delta) hit = true;
-        else if (tmin > tmax + delta) hit = false;
-        else hit = box_exact(mnx, mny, mnz, mxx, mxy, mxz, r.o, r.d, tmin, tmax);
+        bool clear_miss = tmin > tmax + delta;
+        bool clear_hit = tmin <= tmax - delta;
+        hit = !clear_miss;
+        if (exact && !clear_miss && !clear_hit) hit = box_exact(mnx, mny, mnz, mxx, mxy, mxz, r.o, r.d, tmin, tmax);
     } else {
         hit = box_exact(mnx, mny, mnz, mxx, mxy, mxz, r.o, r.d, tmin, tmax);
     }
     t_entry = tmin;
-    if (REF) return hit;
+    if (!prune) return hit;
     return hit && !(tmax < -r.slack0) && !(tmin > limit_plus);
 }
 
@@ -285,9 +299,61 @@ struct TravOut {
     uint32_t nodes, prims;
 };
 
+// Loads through the constant address space: with a wave-uniform address hipcc emits s_load
+// (scalar cache) instead of a vector memory instruction.  (The host pass of hipcc only
+// parses this function, it never runs it.)
+__device__ __forceinline__ float4 load_uniform(const float4 *p, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const float4 __attribute__((address_space(4))) *cf4p;
+    return ((cf4p)(unsigned long long)p)[k];
+#else
+    return p[k];
+#endif
+}
+constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the descent loop
+
+// Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
+// out [entry][thread] so a wave's accesses are conflict-free, overflowing to global memory.
+struct Stack {
+    uint32_t *lds_ref;
+    float *lds_t;
+    uint32_t *spill_ref;
+    float *spill_t;
+    uint32_t spill_stride;
+    int sp;
+    __device__ __forceinline__ void push(uint32_t ref, float t) {
+        if (sp < LDS_STACK) {
+            lds_ref[sp * BLOCK] = ref;
+            lds_t[sp * BLOCK] = t;
+        } else {
+            size_t k = (size_t)(sp - LDS_STACK) * spill_stride;
+            spill_ref[k] = ref;
+            spill_t[k] = t;
+        }
+        sp++;
+    }
+    // Pops the next entry whose box can still matter; TRAV_DONE when the stack is empty.
+    __device__ __forceinline__ uint32_t pop(float limit_plus) {
+        while (sp > 0) {
+            sp--;
+            uint32_t ref;
+            float t;
+            if (sp < LDS_STACK) {
+                ref = lds_ref[sp * BLOCK];
+                t = lds_t[sp * BLOCK];
+            } else {
+                size_t k = (size_t)(sp - LDS_STACK) * spill_stride;
+                ref = spill_ref[k];
+                t = spill_t[k];
+            }
+            if (!(t > limit_plus)) return ref;
+        }
+        return TRAV_DONE;
+    }
+};
+
 template <int MODE, bool COUNT, bool REF>
-__device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, uint32_t *lds, uint32_t *spill,
-                                         uint32_t spill_stride, float dist, TravOut &out) {
+__device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, Stack &st, float dist, TravOut &out) {
     out.prim = NO_PRIM;
     out.t = INFINITY;
     out.any = false;
@@ -299,76 +365,126 @@ __device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, uint3
     float limit_plus = INFINITY;
     {
         float te;
-        if (!box_test<REF>(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], r,
-                           limit_plus, te))
+        if (!box_test(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], r,
+                      limit_plus, true, !REF, te))
             return;
     }
-    int sp = 0;
+    st.sp = 0;
     for (;;) {
+#if RTX_WHILE_WHILE
+        // ---- descend through internal nodes until every lane of the wave holds a leaf (or
+        // nothing).  When all descending lanes sit on the SAME node -- the usual case near the
+        // root for the coherent primary / shadow wavefronts -- the 64-byte record is fetched
+        // once through the scalar cache instead of 64 times through the vector memory path.
+        for (;;) {
+            bool internal = !(cur & LEAF_BIT);
+            if (!__any(internal)) break;
+            if (internal) {
+                float4 n0, n1, n2, n3;
+                uint32_t c0 = __builtin_amdgcn_readfirstlane(cur);
+                if (__all(cur == c0)) {
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + c0);
+                    n0 = load_uniform(np, 0);
+                    n1 = load_uniform(np, 1);
+                    n2 = load_uniform(np, 2);
+                    n3 = load_uniform(np, 3);
+                } else {
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+                    n0 = np[0];
+                    n1 = np[1];
+                    n2 = np[2];
+                    n3 = np[3];
+                }
+                if (COUNT) out.nodes++;
+                uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+                float tl, tr;
+                bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, REF || (left & LEAF_BIT), !REF, tl);
+                bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, REF || (right & LEAF_BIT), !REF, tr);
+                if (hl && hr) {
+                    uint32_t near = left, far = right;
+                    float tfar = tr;
+                    if (!REF && tr < tl) {
+                        near = right;
+                        far = left;
+                        tfar = tl;
+                    }
+                    st.push(far, REF ? -INFINITY : tfar);
+                    cur = near;
+                } else if (hl) {
+                    cur = left;
+                } else if (hr) {
+                    cur = right;
+                } else {
+                    cur = st.pop(limit_plus);
+                }
+            }
+        }
+#else
+        // one node or one leaf per iteration, whichever this lane currently holds
         if (!(cur & LEAF_BIT)) {
             const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) out.nodes++;
-            float tl, tr;
-            bool hl = box_test<REF>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, tl);
-            bool hr = box_test<REF>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, tr);
             uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            float tl, tr;
+            bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, REF || (left & LEAF_BIT), !REF, tl);
+            bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, REF || (right & LEAF_BIT), !REF, tr);
             if (hl && hr) {
                 uint32_t near = left, far = right;
+                float tfar = tr;
                 if (!REF && tr < tl) {
                     near = right;
                     far = left;
+                    tfar = tl;
                 }
-                if (sp < LDS_STACK) lds[sp * BLOCK] = far;
-                else spill[(size_t)(sp - LDS_STACK) * spill_stride] = far;
-                sp++;
+                st.push(far, REF ? -INFINITY : tfar);
                 cur = near;
-                continue;
-            }
-            if (hl) {
+            } else if (hl) {
                 cur = left;
-                continue;
-            }
-            if (hr) {
+            } else if (hr) {
                 cur = right;
-                continue;
+            } else {
+                cur = st.pop(limit_plus);
             }
-        } else {
-            uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
-            bool stop = false;
-            for (uint32_t k = 0; k < cnt; k++) {
-                float tw;
-                if (COUNT) out.prims++;
-                if (prim_intersect(sc.prims + first + k, r, sc.xforms, tw)) {
-                    if (MODE == 0) {
-                        uint32_t pi = first + k;
-                        if (!out.any || tw < out.t || (tw == out.t && pi < out.prim)) {
-                            out.any = true;
-                            out.t = tw;
-                            out.prim = pi;
-                            limit_plus = tw + (r.slack0 + 1.5e-5f * fabsf(tw));
-                        }
-                    } else if (MODE == 1) {
+            if (cur == TRAV_DONE) break;
+            continue;
+        }
+#endif
+        if (cur == TRAV_DONE) break;
+        // ---- leaf: test its (<= 4) primitives in Vec order
+        uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
+        bool stop = false;
+        for (uint32_t k = 0; k < cnt; k++) {
+            float tw;
+            if (COUNT) out.prims++;
+            if (prim_intersect(sc.prims + first + k, r, sc.xforms, tw)) {
+                if (MODE == 0) {
+                    uint32_t pi = first + k;
+                    if (!out.any || tw < out.t || (tw == out.t && pi < out.prim)) {
                         out.any = true;
-                        if (tw + 1e-4f < dist) {
-                            out.occluded = true;
-                            stop = true;
-                            break;
-                        }
-                        limit_plus = dist + (r.slack0 + 1.5e-5f * fabsf(dist));
-                    } else {
-                        out.any = true;
+                        out.t = tw;
+                        out.prim = pi;
+                        if (!REF) limit_plus = tw + (r.slack0 + 1.5e-5f * fabsf(tw));
+                    }
+                } else if (MODE == 1) {
+                    out.any = true;
+                    if (tw + 1e-4f < dist) {
                         out.occluded = true;
                         stop = true;
                         break;
                     }
+                    if (!REF) limit_plus = dist + (r.slack0 + 1.5e-5f * fabsf(dist));
+                } else {
+                    out.any = true;
+                    out.occluded = true;
+                    stop = true;
+                    break;
                 }
             }
-            if (stop) break;
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (sp < LDS_STACK) ? lds[sp * BLOCK] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
+        if (stop) break;
+        cur = st.pop(limit_plus);
+        if (cur == TRAV_DONE) break;
     }
 }
 
@@ -441,14 +557,20 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 
 // ---------------------------------------------------------------- trace_closest
 template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(BLOCK) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint32_t lds_stack[LDS_STACK * BLOCK];
+__global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ uint32_t lds_ref[LDS_STACK * BLOCK];
+    __shared__ float lds_t[LDS_STACK * BLOCK];
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t *lds = lds_stack + threadIdx.x;
-    uint32_t *spill = fr.spill + gtid;
+    Stack st;
+    st.lds_ref = lds_ref + threadIdx.x;
+    st.lds_t = lds_t + threadIdx.x;
+    st.spill_ref = fr.spill + gtid;
+    st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
+    st.spill_stride = nthreads;
+    st.sp = 0;
     uint32_t vn = 0, vp = 0;
     uint32_t *work = fr.counters + CTR_WORK + level * CTR_WORK_STRIDE;
     for (;;) {
@@ -463,7 +585,7 @@ __global__ void __launch_bounds__(BLOCK) trace_closest_kernel(DeviceScene sc, Fr
         RayCtx r;
         init_ray(r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
         TravOut out;
-        traverse<0, COUNT, REF>(sc, r, lds, spill, nthreads, 0.0f, out);
+        traverse<0, COUNT, REF>(sc, r, st, 0.0f, out);
         fr.ray_o[node].w = out.any ? out.t : 0.0f;
         fr.ray_d[node].w = __uint_as_float(out.prim);
         if (COUNT) {
@@ -675,12 +797,18 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 
 // ---------------------------------------------------------------- trace_shadow
 template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint32_t lds_stack[LDS_STACK * BLOCK];
+__global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ uint32_t lds_ref[LDS_STACK * BLOCK];
+    __shared__ float lds_t[LDS_STACK * BLOCK];
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t *lds = lds_stack + threadIdx.x;
-    uint32_t *spill = fr.spill + gtid;
+    Stack st;
+    st.lds_ref = lds_ref + threadIdx.x;
+    st.lds_t = lds_t + threadIdx.x;
+    st.spill_ref = fr.spill + gtid;
+    st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
+    st.spill_stride = nthreads;
+    st.sp = 0;
     uint32_t vn = 0, vp = 0;
     for (uint32_t l = 0; l < sc.n_lights; l++) {
         const LightRec &L = sc.lights[l];
@@ -708,7 +836,7 @@ __global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Fra
                 F3 ro = p + 1e-4f * rd;
                 rd = normalize(rd);
                 init_ray(r, sc, ro, rd);
-                traverse<2, COUNT, REF>(sc, r, lds, spill, nthreads, 0.0f, out);
+                traverse<2, COUNT, REF>(sc, r, st, 0.0f, out);
                 reaches = !out.any;
             } else {
                 // Light::in_shadow (light.rs:81-97)
@@ -716,7 +844,7 @@ __global__ void __launch_bounds__(BLOCK) trace_shadow_kernel(DeviceScene sc, Fra
                 F3 rd = normalize(ldv);
                 float dist = magnitude(lpos - p);
                 init_ray(r, sc, lpos, rd);
-                traverse<1, COUNT, REF>(sc, r, lds, spill, nthreads, dist, out);
+                traverse<1, COUNT, REF>(sc, r, st, dist, out);
                 reaches = out.any && !out.occluded;
             }
             if (reaches) atomicOr(&fr.link[node].x, 1u << l);
@@ -965,7 +1093,6 @@ int query_persistent_blocks(int device) {
             hipSuccess ||
         per_cu < 1)
         per_cu = 4;
-    if (per_cu > 6) per_cu = 6;  // 24 KB of LDS stack per block
     return prop.multiProcessorCount * per_cu;
 }
 

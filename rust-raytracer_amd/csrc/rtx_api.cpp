@@ -160,7 +160,7 @@ int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&c->fr.shadow_q, (size_t)nl * q_cap * sizeof(uint32_t)));
     HIP_TRY(c, alloc((void **)&c->fr.counters, CTR_WORDS * sizeof(uint32_t)));
     size_t threads = (size_t)c->persistent_blocks * 256;
-    HIP_TRY(c, alloc((void **)&c->fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&c->fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
     c->node_cap = node_cap;
     c->q_cap = q_cap;
     c->cap0 = n0;

@@ -11,7 +11,7 @@ calls = defaultdict(set)
 for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        k = k.split("(")[0].replace("void rtx::(anonymous namespace)::", "").replace("rtx::(anonymous namespace)::", "")
+        k = k.replace("void ", "").replace("rtx::(anonymous namespace)::", "").split("(rtx::")[0]
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[k].add((f, row["Dispatch_Id"]))
 for k in sorted(tot):

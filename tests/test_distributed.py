@@ -1,0 +1,62 @@
+"""Tile partition + framebuffer gather with world_size 2 over gloo (CPU).
+
+The oracle stands in for each rank's device renderer (tests may use it): what is checked is
+the product's partition / packing / all-gather / de-interleave logic (rust-raytracer_amd/tiles.py),
+the same code bench.py runs over RCCL."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, width, tile, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt = importlib.import_module("rust-raytracer_amd")
+    tl = importlib.import_module("rust-raytracer_amd.tiles")
+    import orc
+    scene = rt.HostScene("basic", width)
+    o = orc.Scene(scene)
+    full, _ = o.render(spp=1, bounces=3, threads=2)
+    mine = tl.pack_region(torch.from_numpy(full), tile, rank, world)   # this rank's tiles only
+    img = tl.gather_image(mine, width, width, tile, rank, world, dist)
+    np.save(os.path.join(out_dir, f"img{rank}.npy"), img.numpy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full.npy"), full)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("width,tile", [(64, 32), (100, 32), (40, 16)])
+def test_two_rank_gather_matches_full_image(tmp_path, width, tile):
+    port = 29500 + (os.getpid() + width) % 2000
+    mp.spawn(_worker, args=(2, port, width, tile, str(tmp_path)), nprocs=2, join=True)
+    full = np.load(tmp_path / "full.npy")
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"img{r}.npy"), full)
+
+
+def test_partition_counts():
+    tl = importlib.import_module("rust-raytracer_amd.tiles")
+    for w, t, n in [(1024, 32, 8), (100, 32, 3), (500, 32, 8), (33, 8, 5)]:
+        tx, ty = tl.tiles_xy(w, w, t)
+        assert sum(tl.local_tile_count(w, w, t, r, n) for r in range(n)) == tx * ty
+        assert tl.padded_tiles_per_rank(w, w, t, n) == max(tl.local_tile_count(w, w, t, r, n) for r in range(n))
+
+
+def test_assemble_single_rank_roundtrip():
+    tl = importlib.import_module("rust-raytracer_amd.tiles")
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 255, (70, 70, 3), dtype=np.uint8))
+    for n in (1, 2, 3):
+        packs = torch.stack([tl.pack_region(img, 16, r, n) for r in range(n)])
+        assert torch.equal(tl.assemble(packs, 70, 70, 16, n), img)

@@ -1,0 +1,188 @@
+"""Host-side logic of the backend, no GPU needed: the C-ABI library loads and exports what
+include/*.h declares, the BVH builder reproduces the oracle's (= the reference's) topology,
+the on-disk formats decode, and the oracle still matches its committed golden vectors."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "golden.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_exports_every_declared_symbol(rt):
+    lib = rt.lib()
+    names = []
+    for h in ("rtx.h", "rtx_host.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(rtx_[a-z0-9_]+)\s*\(", text)
+    names = sorted(set(names))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+
+
+def test_scene_desc_layout_matches_oracle(rt):
+    """rtx_scene_desc and orc_scene_desc are declared separately; field order must agree."""
+    def fields(path, struct):
+        text = open(path).read()
+        body = text[text.index("typedef struct " + struct):]
+        body = body[:body.index("} " + struct)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split("{", 1)[1].split(";"):
+            decl = decl.strip()
+            if decl:
+                out.append(re.sub(r"\s+", " ", decl))
+        return out
+    a = fields(os.path.join(ROOT, "include", "rtx.h"), "rtx_scene_desc")
+    b = fields(os.path.join(ROOT, "oracle", "oracle.h"), "orc_scene_desc")
+    assert a == b
+
+
+def test_no_gpu_means_loud_failure(rt):
+    """Without a usable HIP device rtx_init must fail (no CPU fallback in the product)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtxError) as e:
+        rt.Context(0)
+    assert e.value.status == rt.RTX_ERR_HIP
+
+
+@pytest.mark.parametrize("name,param", [("basic", 0), ("random_spheres", 1000), ("suzanne", 0), ("basic_suzanne", 0),
+                                        ("scan", 60000), ("scan_glass", 5000), ("soup", 30000)])
+def test_bvh_builder_topology_equals_oracle(rt, orc, name, param):
+    s = rt.HostScene(name, 32, param)
+    leaf_h, pre_h, depth_h, sa_h, n_int = rt.host_bvh_digest(s, threads=4)
+    leaf_o, pre_o, depth_o, sa_o = orc.Scene(s).bvh_digest()
+    assert np.array_equal(leaf_h, leaf_o)
+    assert np.array_equal(pre_h, pre_o)
+    assert depth_h == depth_o and sa_h == sa_o
+    assert n_int == (len(pre_o) - 1) // 2
+
+
+def test_bvh_builder_is_thread_count_invariant(rt):
+    s = rt.HostScene("scan", 32, 150000)
+    ref = rt.host_bvh_digest(s, threads=1)
+    for t in (2, 8):
+        got = rt.host_bvh_digest(s, threads=t)
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and ref[2:] == got[2:]
+
+
+def test_bvh_digests_match_golden(rt):
+    for key, (name, param) in {"bvh_suzanne_0": ("suzanne", 0), "bvh_soup_10000": ("soup", 10000),
+                               "bvh_scan_100000": ("scan", 100000)}.items():
+        leaf, pre, depth, sa, _ = rt.host_bvh_digest(rt.HostScene(name, 32, param))
+        g = META[key]
+        assert _sha(leaf) == g["leaf_order_sha256"] and _sha(pre) == g["preorder_sizes_sha256"]
+        assert depth == g["bvh_depth"] and len(pre) == g["bvh_nodes"] and sa == np.float32(g["total_sa"])
+
+
+def test_degenerate_build_is_reported(rt):
+    objs = [("sphere", (1, 2, 3), 0.5 + 0.1 * i) for i in range(7)]   # identical centroids
+    with pytest.raises(rt.RtxError) as e:
+        rt.host_bvh_digest(rt.ArrayScene(objs))
+    assert e.value.status == rt.RTX_ERR_DEGENERATE
+    # <= 4 such objects are a single leaf, as in the reference (bvh.rs:336)
+    leaf, pre, depth, sa, n_int = rt.host_bvh_digest(rt.ArrayScene(objs[:4]))
+    assert list(pre) == [4] and depth == 0 and n_int == 0
+
+
+def test_empty_and_tiny_scenes(rt, orc):
+    leaf, pre, depth, sa, n_int = rt.host_bvh_digest(rt.ArrayScene([]))
+    assert len(leaf) == 0 and len(pre) == 0
+    s = rt.ArrayScene([("triangle", (0, 0, 1), (0, 1, 1), (1, 0, 1))])
+    leaf, pre, depth, sa, n_int = rt.host_bvh_digest(s)
+    assert list(leaf) == [0] and list(pre) == [1]
+
+
+def test_oracle_matches_golden_vectors(rt, orc):
+    for key, g in META.items():
+        if "_spp" not in key:
+            continue
+        name, width, param, spp = re.match(r"(.+)_(\d+)_(\d+)_spp(\d+)", key).groups()
+        width, param, spp = int(width), int(param), int(spp)
+        gold = np.load(os.path.join(GOLD, key + ".npz"))
+        o = orc.Scene(rt.HostScene(name, width, param))
+        img, st = o.render(spp=spp, bounces=4, seed=1, threads=4)
+        obj, t = o.trace_primary(sample=spp - 1, use_jitter=spp > 1, seed=1)
+        assert np.array_equal(obj, gold["obj"])
+        assert np.array_equal(t.view(np.uint32), gold["t"].view(np.uint32))
+        d = np.abs(img.astype(int) - gold["img"].astype(int)).max(axis=2)
+        assert (d <= 1).mean() >= 0.999        # libm (acos/atan2/pow) may differ between glibc builds
+        assert st.primary_rays == g["primary"]
+        assert abs(st.shadow_rays - g["shadow"]) <= 4 and abs(st.bounce_rays - g["bounce"]) <= 2
+        leaf, pre, depth, sa = o.bvh_digest()
+        assert _sha(leaf) == g["leaf_order_sha256"] and depth == g["bvh_depth"]
+
+
+def test_jitter_hash_golden(orc):
+    for k, v in META["jitter_u32"].items():
+        seed, px, py, s, d = (int(x) for x in k.split(","))
+        assert orc.jitter_u32(seed, px, py, s, d) == v
+
+
+def test_png_decoder_matches_pil_fixture(rt):
+    tex = rt.png_read(os.path.join(ROOT, "assets", "texture.png"))
+    gold = np.load(os.path.join(GOLD, "texture_rgb.npz"))["rgb"]
+    assert tex.shape == (256, 256, 3) and np.array_equal(tex, gold)
+
+
+def test_png_roundtrip(rt, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    rt.png_write(p, img)
+    assert np.array_equal(rt.png_read(p), img)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p)), img)
+    with pytest.raises(rt.RtxError):
+        rt.png_read(str(tmp_path / "missing.png"))
+
+
+def test_suzanne_obj_ingestion(rt):
+    """object.rs:30-91: 500 polygons, 468 quads + 32 triangles, one shared transform and material."""
+    s = rt.HostScene("suzanne", 16)
+    d = s.desc.contents
+    types = np.ctypeslib.as_array(d.obj_type, shape=(d.n_objects,))
+    assert d.n_objects == 500 and (types == 2).sum() == 468 and (types == 1).sum() == 32
+    assert d.n_xforms == 1 and d.n_materials == 1 and d.n_lights == 0
+    m = np.ctypeslib.as_array(d.xforms, shape=(32,)).reshape(2, 4, 4)
+    np.testing.assert_allclose(m[0].T @ m[1].T, np.eye(4), atol=1e-6)   # world_to_object is the inverse
+
+
+def test_builtin_scene_inventory(rt):
+    b = rt.HostScene("basic", 16).desc.contents
+    assert (b.n_objects, b.n_lights, b.n_textures) == (5, 5, 1)
+    r = rt.HostScene("random_spheres", 16).desc.contents
+    assert (r.n_objects, r.n_lights) == (1005, 4)           # scene.rs:111-186
+    c2 = rt.HostScene("basic_suzanne", 16).desc.contents
+    assert (c2.n_objects, c2.n_lights) == (505, 6)
+    sc = rt.HostScene("scan", 16, 0).desc.contents
+    assert sc.n_objects == 2374525 + 5
+    with pytest.raises(rt.RtxError):
+        rt.HostScene("nope", 16)
+
+
+def test_default_camera_matrix(rt, orc):
+    """camera.rs:12-26 / scene.rs:218-226: eye (0,1.5,5) looking at the origin."""
+    s = rt.HostScene("basic", 64)
+    c2w = np.array(list(s.desc.contents.camera_to_world), np.float64).reshape(4, 4).T
+    np.testing.assert_allclose(c2w[:3, 3], (0, 1.5, 5), atol=1e-6)
+    fwd = -c2w[:3, 2]
+    np.testing.assert_allclose(fwd, np.array([0, -1.5, -5]) / np.linalg.norm([0, 1.5, 5]), atol=1e-6)
+    np.testing.assert_allclose(c2w[:3, :3].T @ c2w[:3, :3], np.eye(3), atol=1e-6)
+    # centre pixel ray of the oracle points along the camera's forward axis
+    ray = orc.Scene(s).generate_ray(32, 32)
+    np.testing.assert_allclose(ray[3:], fwd, atol=1e-6)
