@@ -17,9 +17,6 @@ namespace rtx {
 namespace {
 
 constexpr int BLOCK = 256;
-#ifndef RTX_WHILE_WHILE
-#define RTX_WHILE_WHILE 0
-#endif
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 4  // waves per SIMD the trace kernels are register-allocated for
 #endif
@@ -299,17 +296,6 @@ struct TravOut {
     uint32_t nodes, prims;
 };
 
-// Loads through the constant address space: with a wave-uniform address hipcc emits s_load
-// (scalar cache) instead of a vector memory instruction.  (The host pass of hipcc only
-// parses this function, it never runs it.)
-__device__ __forceinline__ float4 load_uniform(const float4 *p, int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const float4 __attribute__((address_space(4))) *cf4p;
-    return ((cf4p)(unsigned long long)p)[k];
-#else
-    return p[k];
-#endif
-}
 constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the descent loop
 
 // Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
@@ -371,55 +357,6 @@ __device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, Stack
     }
     st.sp = 0;
     for (;;) {
-#if RTX_WHILE_WHILE
-        // ---- descend through internal nodes until every lane of the wave holds a leaf (or
-        // nothing).  When all descending lanes sit on the SAME node -- the usual case near the
-        // root for the coherent primary / shadow wavefronts -- the 64-byte record is fetched
-        // once through the scalar cache instead of 64 times through the vector memory path.
-        for (;;) {
-            bool internal = !(cur & LEAF_BIT);
-            if (!__any(internal)) break;
-            if (internal) {
-                float4 n0, n1, n2, n3;
-                uint32_t c0 = __builtin_amdgcn_readfirstlane(cur);
-                if (__all(cur == c0)) {
-                    const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + c0);
-                    n0 = load_uniform(np, 0);
-                    n1 = load_uniform(np, 1);
-                    n2 = load_uniform(np, 2);
-                    n3 = load_uniform(np, 3);
-                } else {
-                    const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
-                    n0 = np[0];
-                    n1 = np[1];
-                    n2 = np[2];
-                    n3 = np[3];
-                }
-                if (COUNT) out.nodes++;
-                uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-                float tl, tr;
-                bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, REF || (left & LEAF_BIT), !REF, tl);
-                bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, REF || (right & LEAF_BIT), !REF, tr);
-                if (hl && hr) {
-                    uint32_t near = left, far = right;
-                    float tfar = tr;
-                    if (!REF && tr < tl) {
-                        near = right;
-                        far = left;
-                        tfar = tl;
-                    }
-                    st.push(far, REF ? -INFINITY : tfar);
-                    cur = near;
-                } else if (hl) {
-                    cur = left;
-                } else if (hr) {
-                    cur = right;
-                } else {
-                    cur = st.pop(limit_plus);
-                }
-            }
-        }
-#else
         // one node or one leaf per iteration, whichever this lane currently holds
         if (!(cur & LEAF_BIT)) {
             const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
@@ -449,7 +386,6 @@ __device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, Stack
             if (cur == TRAV_DONE) break;
             continue;
         }
-#endif
         if (cur == TRAV_DONE) break;
         // ---- leaf: test its (<= 4) primitives in Vec order
         uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
