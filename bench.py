@@ -122,8 +122,15 @@ def main():
     launches_per_step = k_l / args.steps
     avg_launch_ms = k_ms / max(k_l, 1)
     achieved = (k_bytes / max(launches_per_step, 1)) / (avg_launch_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # written by tests/pmc_summary.py from the rocprofv3 --pmc passes
+    if os.path.exists(tpath) and args.scene == "scan" and args.tris == 0 and args.width == 1024 and args.spp == 16 and world == 1:
+        tj = json.load(open(tpath)).get(kname + "_kernel<false, false>")
+        if tj:
+            traffic = int(tj["fetch_bytes_per_launch"])
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(k_bytes / max(launches_per_step, 1)),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_step": int(k_bytes), "rays_per_step": int(k_rays),
                 "bytes_per_ray": round(k_bytes / max(k_rays, 1), 1),

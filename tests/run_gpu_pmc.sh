@@ -8,6 +8,10 @@ run_pass () {
   name=$1; shift
   timeout -s KILL 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc -o $name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc/$name.log 2>&1 || { tail -20 $R/gpurun_out/pmc/$name.log; exit 1; }
 }
+if [ "$1" = "rdreq" ]; then
+run_pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+exit 0
+fi
 if [ "$1" = "mem" ]; then
 run_pass ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCP_LATENCY_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY && \
 run_pass tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_VMEM_RD
