@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RAY_IO_BYTES = 40      # 32 B ray in + 8 B hit out
+NODE_BYTES = 128       # one wide node (two tree levels) = one 128-byte line
+PRIM_BYTES = 64
 
 
 def main():
@@ -113,8 +115,8 @@ def main():
     s_l = sum(s.shadow_launches for s in stats)
     c_rays = counted.primary_rays + counted.bounce_rays
     s_rays = counted.shadow_rays
-    c_bytes = 64 * (counted.closest_nodes + counted.closest_prims) + RAY_IO_BYTES * c_rays
-    s_bytes = 64 * (counted.shadow_nodes + counted.shadow_prims) + RAY_IO_BYTES * s_rays
+    c_bytes = NODE_BYTES * counted.closest_nodes + PRIM_BYTES * counted.closest_prims + RAY_IO_BYTES * c_rays
+    s_bytes = NODE_BYTES * counted.shadow_nodes + PRIM_BYTES * counted.shadow_prims + RAY_IO_BYTES * s_rays
     if s_ms >= c_ms:
         kname, k_ms, k_l, k_bytes, k_rays = "trace_shadow", s_ms, s_l, s_bytes, s_rays
     else:

@@ -20,6 +20,23 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node must be one cache line");
 
+// Two levels of the same tree fetched as ONE 128-byte line (the L2 / fabric line size on
+// MI355X): the boxes of up to four descendants of a reference node, obtained by repeatedly
+// replacing the internal slot of largest surface area by its two children.  Every slot is
+// a node of the reference tree with the reference's box; leaves are never merged or
+// split, so leaf contents, leaf order and leaf boxes are exactly bvh.rs's.  Slot reference:
+// bit 31 set = leaf (same encoding as BvhNode), else index of the wide node of that
+// internal reference node; WIDE_EMPTY = unused slot.  Boxes are stored per axis for the
+// four slots (SoA) so one dwordx4 load feeds four slab computations.
+struct alignas(128) WideNode {
+    float mnx[4], mny[4], mnz[4];
+    float mxx[4], mxy[4], mxz[4];
+    uint32_t ref[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "wide node must be one 128-byte line");
+constexpr uint32_t WIDE_EMPTY = 0xFFFFFFFFu;
+
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t INVALID_PRIM = 0xFFFFFFFEu;  // sample slot outside the image
@@ -86,6 +103,6 @@ constexpr int MAX_COMP_DEPTH = 4;      // nesting of Composition
 #define RTX_LDS_STACK 16
 #endif
 constexpr int LDS_STACK = RTX_LDS_STACK;          // per-lane traversal stack entries kept in LDS
-constexpr int MAX_TREE_DEPTH = 120;    // LDS_STACK + global spill entries per lane
+constexpr int MAX_TREE_DEPTH = 200;    // LDS_STACK + global spill entries per lane
 
 }  // namespace rtx

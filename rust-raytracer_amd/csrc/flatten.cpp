@@ -47,6 +47,79 @@ struct Emit {
     }
 };
 
+// Wide (up to 4 slots) view of the same tree; see WideNode in device_types.h.
+struct EmitWide {
+    const BuiltBvh &bvh;
+    FlatScene &out;
+
+    static float sa(const BuildNode &n) {
+        float dx = n.mx[0] - n.mn[0], dy = n.mx[1] - n.mn[1], dz = n.mx[2] - n.mn[2];
+        return 2.0f * dx * dy + 2.0f * dx * dz + 2.0f * dz * dy;
+    }
+    static uint32_t leaf_ref(const BuildNode &n) { return LEAF_BIT | (n.first << 3) | n.count; }
+
+    // Iterative (explicit work list): the tree can be deep.
+    void run(int32_t root) {
+        struct Item {
+            int32_t bn;
+            uint32_t widx, level;
+        };
+        std::vector<Item> work;
+        out.wnodes.emplace_back();
+        work.push_back({root, 0, 1});
+        while (!work.empty()) {
+            Item it = work.back();
+            work.pop_back();
+            if (it.level > out.wide_depth) out.wide_depth = it.level;
+            const BuildNode &n = bvh.nodes[it.bn];
+            int32_t slots[4] = {n.left, n.right, -1, -1};
+            int ns = 2;
+            while (ns < 4) {  // expand the internal slot of largest surface area
+                int best = -1;
+                float best_sa = -1.0f;
+                for (int k = 0; k < ns; k++) {
+                    const BuildNode &c = bvh.nodes[slots[k]];
+                    if (c.left < 0) continue;
+                    float a = sa(c);
+                    if (!(a == a)) a = INFINITY;
+                    if (best < 0 || a > best_sa) {
+                        best = k;
+                        best_sa = a;
+                    }
+                }
+                if (best < 0) break;
+                const BuildNode &c = bvh.nodes[slots[best]];
+                // keep left-to-right order: the two children take the place of their parent
+                for (int k = ns; k > best + 1; k--) slots[k] = slots[k - 1];
+                slots[best] = c.left;
+                slots[best + 1] = c.right;
+                ns++;
+            }
+            WideNode w;
+            std::memset(&w, 0, sizeof(w));
+            for (int k = 0; k < 4; k++) w.ref[k] = WIDE_EMPTY;
+            for (int k = 0; k < ns; k++) {
+                const BuildNode &c = bvh.nodes[slots[k]];
+                w.mnx[k] = c.mn[0];
+                w.mny[k] = c.mn[1];
+                w.mnz[k] = c.mn[2];
+                w.mxx[k] = c.mx[0];
+                w.mxy[k] = c.mx[1];
+                w.mxz[k] = c.mx[2];
+                if (c.left < 0) {
+                    w.ref[k] = leaf_ref(c);
+                } else {
+                    uint32_t ci = (uint32_t)out.wnodes.size();
+                    out.wnodes.emplace_back();
+                    w.ref[k] = ci;
+                    work.push_back({slots[k], ci, it.level + 1});
+                }
+            }
+            out.wnodes[it.widx] = w;
+        }
+    }
+};
+
 // Material tree -> post-order program (material.rs:118-206).
 int emit_material(const rtx_scene_desc &d, int node, int depth, std::vector<MatInstr> &prog, uint32_t &n_bounce,
                   std::string &err) {
@@ -191,7 +264,8 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
     }
     // primitives in leaf order
     uint32_t n = d.n_objects;
-    out.prims.resize(n);
+    out.prims.resize((size_t)n + 3);  // 3 zero records of padding: a leaf visit touches first..first+3
+    std::memset(out.prims.data() + n, 0, 3 * sizeof(Prim));
     out.prim_obj = bvh.leaf_order;
     for (uint32_t k = 0; k < n; k++) {
         uint32_t o = bvh.leaf_order[k];
@@ -230,6 +304,14 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         float total = 0.0f;
         out.root_ref = e.emit(0, total);
         out.total_sa = total;
+        if (bvh.nodes[0].left < 0) {
+            out.wide_root_ref = out.root_ref;
+        } else {
+            EmitWide w{bvh, out};
+            out.wnodes.reserve(bvh.nodes.size() / 4 + 1);
+            w.run(0);
+            out.wide_root_ref = 0;
+        }
         for (int k = 0; k < 3; k++) {
             out.root_mn[k] = bvh.nodes[0].mn[k];
             out.root_mx[k] = bvh.nodes[0].mx[k];

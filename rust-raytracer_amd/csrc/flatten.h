@@ -10,6 +10,9 @@ namespace rtx {
 
 struct FlatScene {
     std::vector<BvhNode> nodes;         // internal nodes, DFS preorder (root = 0)
+    std::vector<WideNode> wnodes;       // the same tree, two levels per 128-byte record (root = 0)
+    uint32_t wide_root_ref = NO_PRIM;   // wide node 0, or the root leaf reference
+    uint32_t wide_depth = 0;            // levels of wide nodes above the deepest leaf
     std::vector<Prim> prims;            // leaf order
     std::vector<uint32_t> prim_obj;     // leaf order -> object index
     std::vector<Xform> xforms;

@@ -9,7 +9,8 @@ namespace rtx {
 
 // Scene as the kernels see it: pointers into HBM plus the small constants.
 struct DeviceScene {
-    const BvhNode *nodes;
+    const BvhNode *nodes;       // binary nodes: RTX_FLAG_REFERENCE_TRAVERSAL only
+    const WideNode *wnodes;     // the same tree, two levels per 128-byte line (production traversal)
     const Prim *prims;
     const Xform *xforms;
     const MaterialRec *mats;
@@ -20,6 +21,7 @@ struct DeviceScene {
     const uint32_t *prim_obj;   // leaf-order primitive -> object index of the description
     uint32_t n_prims, n_lights;
     uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
+    uint32_t wroot_ref;         // root in the wide tree (wide node 0 or the root leaf)
     float root_mn[3], root_mx[3];
     float coord_scale;          // largest |coordinate| of the root box (pruning slack)
     float background[3];

@@ -289,13 +289,6 @@ __device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const 
 // MODE 1: light.rs:81-97 as any-hit: stop at the first hit with t + 1e-4 < dist;
 //         otherwise report whether anything was hit at all.
 // MODE 2: directional light (light.rs:106-112): stop at the first hit.
-struct TravOut {
-    uint32_t prim;
-    float t;
-    bool any, occluded;
-    uint32_t nodes, prims;
-};
-
 constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the descent loop
 
 // Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
@@ -338,91 +331,202 @@ struct Stack {
     }
 };
 
-template <int MODE, bool COUNT, bool REF>
-__device__ __forceinline__ void traverse(const DeviceScene &sc, RayCtx &r, Stack &st, float dist, TravOut &out) {
-    out.prim = NO_PRIM;
-    out.t = INFINITY;
-    out.any = false;
-    out.occluded = false;
-    out.nodes = 0;
-    out.prims = 0;
-    uint32_t cur = sc.root_ref;
-    if (cur == NO_PRIM) return;
-    float limit_plus = INFINITY;
-    {
-        float te;
-        if (!box_test(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], r,
-                      limit_plus, true, !REF, te))
-            return;
-    }
+// Compare-exchange of two (entry t, reference) pairs: afterwards ta <= tb.
+__device__ __forceinline__ void cswap(float &ta, uint32_t &ra, float &tb, uint32_t &rb) {
+    bool sw = tb < ta;
+    float tlo = sw ? tb : ta, thi = sw ? ta : tb;
+    uint32_t rlo = sw ? rb : ra, rhi = sw ? ra : rb;
+    ta = tlo;
+    tb = thi;
+    ra = rlo;
+    rb = rhi;
+}
+
+// One slot of a wide node: box decision + pruning; a rejected slot gets (INF, WIDE_EMPTY).
+__device__ __forceinline__ void wide_slot(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, uint32_t ref,
+                                          const RayCtx &r, float limit_plus, float &t, uint32_t &rr) {
+    bool valid = ref != WIDE_EMPTY;
+    float te;
+    bool hit = box_test(mnx, mny, mnz, mxx, mxy, mxz, r, limit_plus, valid && (ref & LEAF_BIT), true, te);
+    hit = hit && valid;
+    t = hit ? fminf(te, 3.0e38f) : INFINITY;
+    rr = hit ? ref : WIDE_EMPTY;
+}
+
+// Traversal state of one lane.  trav_begin() starts a ray, trav_step() advances it by one
+// wide node or one leaf; cur == TRAV_DONE when the ray has its answer.
+// REF = false: production traversal over the wide nodes (ordered, pruned).
+// REF = true:  bvh.rs:359-395 verbatim over the binary nodes (both children, no pruning).
+struct Trav {
+    RayCtx r;
+    uint32_t cur;
+    float limit_plus;
+    uint32_t prim;
+    float t;
+    bool any, occluded;
+    uint32_t nodes, prims;  // visit counters, accumulated over the lane's rays (COUNT)
+};
+
+template <bool REF>
+__device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack &st) {
+    s.prim = NO_PRIM;
+    s.t = INFINITY;
+    s.any = false;
+    s.occluded = false;
+    s.limit_plus = INFINITY;
+    s.cur = TRAV_DONE;
     st.sp = 0;
-    for (;;) {
-        // one node or one leaf per iteration, whichever this lane currently holds
-        if (!(cur & LEAF_BIT)) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
-            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT) out.nodes++;
-            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-            float tl, tr;
-            bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, limit_plus, REF || (left & LEAF_BIT), !REF, tl);
-            bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, limit_plus, REF || (right & LEAF_BIT), !REF, tr);
-            if (hl && hr) {
-                uint32_t near = left, far = right;
-                float tfar = tr;
-                if (!REF && tr < tl) {
-                    near = right;
-                    far = left;
-                    tfar = tl;
-                }
-                st.push(far, REF ? -INFINITY : tfar);
-                cur = near;
-            } else if (hl) {
-                cur = left;
-            } else if (hr) {
-                cur = right;
-            } else {
-                cur = st.pop(limit_plus);
+    uint32_t root = REF ? sc.root_ref : sc.wroot_ref;
+    if (root == NO_PRIM) return;
+    float te;
+    if (box_test(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], s.r,
+                 s.limit_plus, true, !REF, te))
+        s.cur = root;
+}
+
+// Advances a lane that holds an internal node by one node.
+template <bool COUNT, bool REF>
+__device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st) {
+    uint32_t cur = s.cur;
+    if (COUNT) s.nodes++;
+    if constexpr (!REF) {
+        const float4 *np = reinterpret_cast<const float4 *>(sc.wnodes + cur);
+        float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
+        float4 rf4 = np[6];
+        float t0, t1, t2, t3;
+        uint32_t r0, r1, r2, r3;
+        wide_slot(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, __float_as_uint(rf4.x), s.r, s.limit_plus, t0, r0);
+        wide_slot(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, __float_as_uint(rf4.y), s.r, s.limit_plus, t1, r1);
+        wide_slot(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, __float_as_uint(rf4.z), s.r, s.limit_plus, t2, r2);
+        wide_slot(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, __float_as_uint(rf4.w), s.r, s.limit_plus, t3, r3);
+        // sort the four slots by entry t (rejected slots last): the nearest is continued,
+        // the others are pushed farthest first
+        cswap(t0, r0, t1, r1);
+        cswap(t2, r2, t3, r3);
+        cswap(t0, r0, t2, r2);
+        cswap(t1, r1, t3, r3);
+        cswap(t1, r1, t2, r2);
+        if (r1 != WIDE_EMPTY) {
+            if (r2 != WIDE_EMPTY) {
+                if (r3 != WIDE_EMPTY) st.push(r3, t3);
+                st.push(r2, t2);
             }
-            if (cur == TRAV_DONE) break;
-            continue;
+            st.push(r1, t1);
         }
-        if (cur == TRAV_DONE) break;
-        // ---- leaf: test its (<= 4) primitives in Vec order
-        uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
-        bool stop = false;
-        for (uint32_t k = 0; k < cnt; k++) {
-            float tw;
-            if (COUNT) out.prims++;
-            if (prim_intersect(sc.prims + first + k, r, sc.xforms, tw)) {
-                if (MODE == 0) {
-                    uint32_t pi = first + k;
-                    if (!out.any || tw < out.t || (tw == out.t && pi < out.prim)) {
-                        out.any = true;
-                        out.t = tw;
-                        out.prim = pi;
-                        if (!REF) limit_plus = tw + (r.slack0 + 1.5e-5f * fabsf(tw));
-                    }
-                } else if (MODE == 1) {
-                    out.any = true;
-                    if (tw + 1e-4f < dist) {
-                        out.occluded = true;
-                        stop = true;
-                        break;
-                    }
-                    if (!REF) limit_plus = dist + (r.slack0 + 1.5e-5f * fabsf(dist));
-                } else {
-                    out.any = true;
-                    out.occluded = true;
-                    stop = true;
-                    break;
-                }
-            }
+        s.cur = (r0 != WIDE_EMPTY) ? r0 : st.pop(s.limit_plus);
+    } else {
+        const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+        float tl, tr;
+        bool hl = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, s.r, s.limit_plus, true, false, tl);
+        bool hr = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, s.r, s.limit_plus, true, false, tr);
+        if (hl && hr) {
+            st.push(right, -INFINITY);
+            s.cur = left;
+        } else if (hl) {
+            s.cur = left;
+        } else if (hr) {
+            s.cur = right;
+        } else {
+            s.cur = st.pop(s.limit_plus);
         }
-        if (stop) break;
-        cur = st.pop(limit_plus);
-        if (cur == TRAV_DONE) break;
     }
 }
+
+// Advances a lane that holds a leaf by ONE primitive (Vec order, bvh.rs:378-389): the leaf
+// reference (first << 3 | count) shrinks from the front until it is used up.
+template <int MODE, bool COUNT, bool REF>
+__device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack &st, float dist) {
+    uint32_t cur = s.cur;
+    uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+    float tw;
+    if (COUNT) s.prims++;
+    if (prim_intersect(sc.prims + first, s.r, sc.xforms, tw)) {
+        if (MODE == 0) {
+            if (!s.any || tw < s.t || (tw == s.t && first < s.prim)) {
+                s.any = true;
+                s.t = tw;
+                s.prim = first;
+                if (!REF) s.limit_plus = tw + (s.r.slack0 + 1.5e-5f * fabsf(tw));
+            }
+        } else if (MODE == 1) {
+            s.any = true;
+            if (tw + 1e-4f < dist) {
+                s.occluded = true;
+                s.cur = TRAV_DONE;
+                return;
+            }
+            if (!REF) s.limit_plus = dist + (s.r.slack0 + 1.5e-5f * fabsf(dist));
+        } else {
+            s.any = true;
+            s.occluded = true;
+            s.cur = TRAV_DONE;
+            return;
+        }
+    }
+    s.cur = ((cur & 7u) > 1u) ? cur + 7u : st.pop(s.limit_plus);  // first + 1, count - 1
+}
+
+// One scheduling step of a wave: lanes are either at an internal node or at a primitive of
+// a leaf; executing both kinds every iteration would run each at a fraction of the lanes.
+// The wave executes ONE kind per step, the one that advances more work (a primitive test
+// counts RTX_LEAF_WEIGHT times a node visit, it is the shorter code), the other lanes wait.
+#ifndef RTX_LEAF_WEIGHT
+#define RTX_LEAF_WEIGHT 1
+#endif
+template <int MODE, bool COUNT, bool REF>
+__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist) {
+    bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
+    bool at_node = !(s.cur & LEAF_BIT);
+    uint32_t nl = (uint32_t)__popcll(__ballot(at_leaf)), nn = (uint32_t)__popcll(__ballot(at_node));
+    if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn) {
+        if (at_leaf) prim_step<MODE, COUNT, REF>(sc, s, st, dist);
+    } else {
+        if (at_node) node_step<COUNT, REF>(sc, s, st);
+    }
+}
+
+// Work distribution of the persistent trace kernels.  A wave owns a private run of
+// consecutive queue entries [next, end) taken from the global queue head with ONE atomic
+// (a single hot counter sustains only ~90 atomics/us), and hands them to its lanes one by
+// one: as soon as REFILL_MIN lanes have finished their ray they get new rays, so lanes do
+// not idle until the longest ray of a 64-ray batch is done.
+#ifndef RTX_REFILL_MIN
+#define RTX_REFILL_MIN 16
+#endif
+struct WaveQueue {
+    uint32_t *head;
+    uint32_t count, chunk;
+    uint32_t next, end;
+    bool exhausted;
+    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nwaves) {
+        head = h;
+        count = n;
+        uint32_t c = n / (nwaves * 4u);
+        chunk = c < 64u ? 64u : (c > 256u ? 256u : c);
+        next = end = 0;
+        exhausted = n == 0;
+    }
+    // Gives every idle lane (ballot `idle`) its queue index; returns false for lanes left empty.
+    __device__ __forceinline__ bool take(unsigned long long idle, bool lane_idle, uint32_t &index) {
+        if (next >= end) {
+            next = wave_fetch(head, chunk);
+            end = next + chunk < count ? next + chunk : count;
+            if (next >= count) {
+                exhausted = true;
+                next = end = count;
+                return false;
+            }
+        }
+        uint32_t avail = end - next, nidle = (uint32_t)__popcll(idle);
+        uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
+        index = next + rank;
+        bool got = lane_idle && rank < avail;
+        next += nidle < avail ? nidle : avail;
+        return got;
+    }
+};
 
 __device__ __forceinline__ void add_visits(uint32_t *ctr, uint32_t nodes, uint32_t prims, int first) {
     // wave reduction, then one 64-bit atomic pair per wave
@@ -497,7 +601,6 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
     __shared__ uint32_t lds_ref[LDS_STACK * BLOCK];
     __shared__ float lds_t[LDS_STACK * BLOCK];
     const uint32_t base = level_base(fr.counters, level);
-    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
@@ -507,29 +610,45 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
     st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
     st.spill_stride = nthreads;
     st.sp = 0;
-    uint32_t vn = 0, vp = 0;
-    uint32_t *work = fr.counters + CTR_WORK + level * CTR_WORK_STRIDE;
+    Trav s;
+    s.cur = TRAV_DONE;
+    s.nodes = s.prims = 0;
+    uint32_t node = 0;
+    WaveQueue wq;
+    wq.init(fr.counters + CTR_WORK + level * CTR_WORK_STRIDE, fr.counters[CTR_LEVEL_COUNT + level], nthreads / 64u);
     for (;;) {
-        // persistent threads: every wave pulls its next 64 rays from the queue head
-        uint32_t i0 = wave_fetch(work, 64u);
-        if (i0 >= count) break;
-        uint32_t i = i0 + lane_id();
-        if (i >= count) continue;
-        uint32_t node = base + i;
-        float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-        if (__float_as_uint(d4.w) == INVALID_PRIM) continue;
-        RayCtx r;
-        init_ray(r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
-        TravOut out;
-        traverse<0, COUNT, REF>(sc, r, st, 0.0f, out);
-        fr.ray_o[node].w = out.any ? out.t : 0.0f;
-        fr.ray_d[node].w = __uint_as_float(out.prim);
-        if (COUNT) {
-            vn += out.nodes;
-            vp += out.prims;
+        unsigned long long idle = __ballot(s.cur == TRAV_DONE);
+        uint32_t nidle = (uint32_t)__popcll(idle);
+        if (wq.exhausted) {
+            if (nidle == 64u) break;
+        } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
+            uint32_t i;
+            if (wq.take(idle, s.cur == TRAV_DONE, i)) {
+                node = base + i;
+                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                if (__float_as_uint(d4.w) != INVALID_PRIM) {
+                    init_ray(s.r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
+                    trav_begin<REF>(sc, s, st);
+                    if (s.cur == TRAV_DONE) {  // misses the root box
+                        fr.ray_o[node].w = 0.0f;
+                        fr.ray_d[node].w = __uint_as_float(NO_PRIM);
+                    }
+                }
+            }
+            continue;
         }
+        // advance the active lanes until enough of them are idle again
+        const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
+        do {
+            bool active = s.cur != TRAV_DONE;
+            wave_step<0, COUNT, REF>(sc, s, st, 0.0f);
+            if (active && s.cur == TRAV_DONE) {
+                fr.ray_o[node].w = s.any ? s.t : 0.0f;
+                fr.ray_d[node].w = __uint_as_float(s.prim);
+            }
+        } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
     }
-    if (COUNT) add_visits(fr.counters, vn, vp, CTR_VISIT_NODES_LO);
+    if (COUNT) add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
 }
 
 // ---------------------------------------------------------------- object.rs helpers for shading
@@ -745,52 +864,65 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
     st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
     st.spill_stride = nthreads;
     st.sp = 0;
-    uint32_t vn = 0, vp = 0;
+    Trav s;
+    s.cur = TRAV_DONE;
+    s.nodes = s.prims = 0;
+    uint32_t node = 0;
+    float dist = 0.0f;
     for (uint32_t l = 0; l < sc.n_lights; l++) {
         const LightRec &L = sc.lights[l];
         if (L.type == LIGHT_AMBIENT) continue;
         uint32_t count = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
         if (count > fr.q_cap) count = fr.q_cap;
         const uint32_t *q = fr.shadow_q + (size_t)l * fr.q_cap;
-        F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
-        F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
-        uint32_t *work = fr.counters + CTR_WORK + level * CTR_WORK_STRIDE + 1 + l;
+        const F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
+        const F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
+        const bool directional = L.type == 2u;
+        WaveQueue wq;
+        wq.init(fr.counters + CTR_WORK + level * CTR_WORK_STRIDE + 1 + l, count, nthreads / 64u);
         for (;;) {
-            uint32_t i0 = wave_fetch(work, 64u);
-            if (i0 >= count) break;
-            uint32_t i = i0 + lane_id();
-            if (i >= count) continue;
-            uint32_t node = q[i];
-            float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-            F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
-            RayCtx r;
-            TravOut out;
-            bool reaches;
-            if (L.type == 2u) {
-                // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
-                F3 rd = normalize(-ldir);
-                F3 ro = p + 1e-4f * rd;
-                rd = normalize(rd);
-                init_ray(r, sc, ro, rd);
-                traverse<2, COUNT, REF>(sc, r, st, 0.0f, out);
-                reaches = !out.any;
-            } else {
-                // Light::in_shadow (light.rs:81-97)
-                F3 ldv = p - lpos;
-                F3 rd = normalize(ldv);
-                float dist = magnitude(lpos - p);
-                init_ray(r, sc, lpos, rd);
-                traverse<1, COUNT, REF>(sc, r, st, dist, out);
-                reaches = out.any && !out.occluded;
+            unsigned long long idle = __ballot(s.cur == TRAV_DONE);
+            uint32_t nidle = (uint32_t)__popcll(idle);
+            if (wq.exhausted) {
+                if (nidle == 64u) break;
+            } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
+                uint32_t i;
+                if (wq.take(idle, s.cur == TRAV_DONE, i)) {
+                    node = q[i];
+                    float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
+                    if (directional) {
+                        // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
+                        F3 rd = normalize(-ldir);
+                        F3 ro = p + 1e-4f * rd;
+                        rd = normalize(rd);
+                        init_ray(s.r, sc, ro, rd);
+                    } else {
+                        // Light::in_shadow (light.rs:81-97)
+                        F3 rd = normalize(p - lpos);
+                        dist = magnitude(lpos - p);
+                        init_ray(s.r, sc, lpos, rd);
+                    }
+                    trav_begin<REF>(sc, s, st);
+                    // a ray that misses the root box hits nothing: directional light reaches,
+                    // point / cone light does not (light.rs:93-96)
+                    if (s.cur == TRAV_DONE && directional) atomicOr(&fr.link[node].x, 1u << l);
+                }
+                continue;
             }
-            if (reaches) atomicOr(&fr.link[node].x, 1u << l);
-            if (COUNT) {
-                vn += out.nodes;
-                vp += out.prims;
-            }
+            const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
+            do {
+                bool active = s.cur != TRAV_DONE;
+                if (directional) wave_step<2, COUNT, REF>(sc, s, st, 0.0f);
+                else wave_step<1, COUNT, REF>(sc, s, st, dist);
+                if (active && s.cur == TRAV_DONE) {
+                    bool reaches = directional ? !s.any : (s.any && !s.occluded);
+                    if (reaches) atomicOr(&fr.link[node].x, 1u << l);
+                }
+            } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
         }
     }
-    if (COUNT) add_visits(fr.counters, vn, vp, CTR_SVISIT_NODES_LO);
+    if (COUNT) add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
 }
 
 // ---------------------------------------------------------------- resolve

@@ -429,17 +429,19 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     int rc = build_bvh(*d, threads, bvh, c->err);
     if (rc != RTX_OK) return rc;
     double t1 = now_s();
-    if (bvh.depth + 2 > (uint32_t)MAX_TREE_DEPTH) {
-        c->err = "BVH deeper than the traversal stack (120)";
-        return RTX_ERR_CAPACITY;
-    }
     FlatScene fs;
     rc = flatten_scene(*d, bvh, fs, c->err);
     if (rc != RTX_OK) return rc;
+    // stack need: one entry per level (reference traversal), up to three per wide level
+    if (bvh.depth + 2 > (uint32_t)MAX_TREE_DEPTH || 3 * fs.wide_depth + 2 > (uint32_t)MAX_TREE_DEPTH) {
+        c->err = "BVH deeper than the traversal stack";
+        return RTX_ERR_CAPACITY;
+    }
     double t2 = now_s();
     DeviceScene &ds = c->ds;
     ds = DeviceScene{};
     if ((rc = upload(c, fs.nodes, &ds.nodes, c->scene_allocs))) return rc;
+    if ((rc = upload(c, fs.wnodes, &ds.wnodes, c->scene_allocs))) return rc;
     if ((rc = upload(c, fs.prims, &ds.prims, c->scene_allocs))) return rc;
     if ((rc = upload(c, fs.xforms, &ds.xforms, c->scene_allocs))) return rc;
     if ((rc = upload(c, fs.mats, &ds.mats, c->scene_allocs))) return rc;
@@ -448,9 +450,10 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if ((rc = upload(c, fs.tex_data, &ds.tex_data, c->scene_allocs))) return rc;
     if ((rc = upload(c, fs.lights, &ds.lights, c->scene_allocs))) return rc;
     if ((rc = upload(c, fs.prim_obj, &ds.prim_obj, c->scene_allocs))) return rc;
-    ds.n_prims = (uint32_t)fs.prims.size();
+    ds.n_prims = d->n_objects;
     ds.n_lights = (uint32_t)fs.lights.size();
     ds.root_ref = fs.root_ref;
+    ds.wroot_ref = fs.wide_root_ref;
     float scale = 0.0f;
     for (int k = 0; k < 3; k++) {
         ds.root_mn[k] = fs.root_mn[k];
