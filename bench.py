@@ -28,6 +28,17 @@ NODE_BYTES = 128       # one wide node (two tree levels) = one 128-byte line
 PRIM_BYTES = 64
 
 
+SCENE_TEXT = {
+    "scan": "load_basic + 4 synthetic scan-like meshes (BASELINE config 3, stand-in for the Stanford scans)",
+    "scan_glass": "config-3 geometry with mirror+glass+Phong compositions (BASELINE config 4)",
+    "soup": "random-triangle soup, 4 point lights + ambient (BASELINE config 5)",
+    "basic_suzanne": "load_basic + Suzanne.obj + directional light (BASELINE config 2)",
+    "random_spheres": "load_random_spheres (BASELINE config 1, what main.rs:90 renders)",
+    "basic": "load_basic (scene.rs:11-108)",
+    "suzanne": "load_suzanne (scene.rs:188-214)",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +171,7 @@ def main():
     out = {"metric": "Mrays/s at 2.3M-tri 1024^2 16spp", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{args.scene}: load_basic + 4 synthetic scan-like meshes, {info.n_objects} primitives, "
+           "config": {"workload": f"{args.scene}: {SCENE_TEXT.get(args.scene, args.scene)}, {info.n_objects} primitives, "
                                   f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
                       "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
                       "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
