@@ -44,8 +44,8 @@ constexpr uint32_t INVALID_PRIM = 0xFFFFFFFEu;  // sample slot outside the image
 // One primitive in leaf order (Object, object.rs:20-26, minus the per-object matrices,
 // which live in the Xform table).  v[0..11]: sphere = centre, radius, radius^2;
 // triangle = a,b,c; quad = a,b,c,d.  n = normalize((b-a)x(c|d - a)) precomputed with the
-// reference's arithmetic (object.rs:168,191).  meta: bits 1..0 type, 15..2 xform id,
-// 31..16 material id.
+// reference's arithmetic (object.rs:168,191).  meta: bits 1..0 type, 14..2 xform id, bit 15 =
+// that transform is exactly the identity, 31..16 material id.
 struct alignas(64) Prim {
     float v[12];
     float n[3];

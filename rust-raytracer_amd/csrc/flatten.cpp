@@ -185,8 +185,8 @@ int emit_material(const rtx_scene_desc &d, int node, int depth, std::vector<MatI
 
 int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err) {
     out = FlatScene();
-    if (d.n_xforms == 0 || d.n_xforms > 16384) {
-        err = "scene needs between 1 and 16384 transforms";
+    if (d.n_xforms == 0 || d.n_xforms > 8192) {
+        err = "scene needs between 1 and 8192 transforms";
         return d.n_xforms == 0 ? RTX_ERR_INVALID : RTX_ERR_CAPACITY;
     }
     if (d.n_materials == 0 || d.n_materials > 65536) {
@@ -202,10 +202,18 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         return RTX_ERR_CAPACITY;
     }
     out.xforms.resize(d.n_xforms);
+    std::vector<uint8_t> xf_identity(d.n_xforms);
     for (uint32_t i = 0; i < d.n_xforms; i++) {
         std::memcpy(out.xforms[i].o2w, d.xforms + (size_t)i * 32, 64);
         std::memcpy(out.xforms[i].w2o, d.xforms + (size_t)i * 32 + 16, 64);
+        bool id = true;
+        for (int k = 0; k < 32; k++) {
+            float want = ((k & 15) % 5 == 0) ? 1.0f : 0.0f;
+            if (d.xforms[(size_t)i * 32 + k] != want || std::signbit(d.xforms[(size_t)i * 32 + k])) id = false;
+        }
+        xf_identity[i] = id;
     }
+    out.xf0_identity = xf_identity[0];
     // materials
     out.mats.resize(d.n_materials);
     std::vector<uint32_t> mat_bounce(d.n_materials);
@@ -294,7 +302,7 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             p.n[1] = nn.y;
             p.n[2] = nn.z;
         }
-        p.meta = (uint32_t)type | ((uint32_t)xf << 2) | ((uint32_t)mat << 16);
+        p.meta = (uint32_t)type | ((uint32_t)xf << 2) | (xf_identity[xf] ? 0x8000u : 0u) | ((uint32_t)mat << 16);
         if (mat_bounce[mat] > out.max_bounce) out.max_bounce = mat_bounce[mat];
     }
     // tree

@@ -22,6 +22,7 @@ struct DeviceScene {
     uint32_t n_prims, n_lights;
     uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
     uint32_t wroot_ref;         // root in the wide tree (wide node 0 or the root leaf)
+    uint32_t xf0_identity;      // transform 0 is exactly the identity
     float root_mn[3], root_mx[3];
     float coord_scale;          // largest |coordinate| of the root box (pruning slack)
     float background[3];
@@ -56,7 +57,7 @@ struct Frame {
     float4 *color;      // resolved colour of the node
     uint32_t *shadow_q; // [MAX_LIGHTS][q_cap] node ids waiting for a shadow query
     uint32_t *counters; // CTR_WORDS
-    uint32_t *spill;    // traversal-stack overflow, [MAX_TREE_DEPTH-LDS_STACK][threads]
+    uint32_t *spill;    // traversal-stack overflow, [MAX_TREE_DEPTH-LDS_STACK][threads] of (ref, t)
     uint32_t node_cap, q_cap;
 };
 

@@ -17,6 +17,7 @@ namespace rtx {
 namespace {
 
 constexpr int BLOCK = 256;
+constexpr uint32_t PRIM_IDENTITY_XFORM = 0x8000u;  // Prim::meta bit 15
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 4  // waves per SIMD the trace kernels are register-allocated for
 #endif
@@ -116,10 +117,17 @@ struct RayCtx {
     float slack0;     // absolute pruning slack
 };
 
-__device__ __forceinline__ void set_xform(RayCtx &r, const Xform *xforms, uint32_t xf) {
-    const float *M = xforms[xf].w2o;
-    r.oo = transform_point(M, r.o);
-    r.od = normalize(transform_vector(M, r.d));
+// `identity`: both matrices of the transform are exactly the identity; M*(p,1) and M*(v,0)
+// then reproduce p and v bit for bit (x*1 + y*0 + z*0 + 0), so the products are skipped.
+__device__ __forceinline__ void set_xform(RayCtx &r, const Xform *xforms, uint32_t xf, bool identity) {
+    if (identity) {
+        r.oo = r.o;
+        r.od = normalize(r.d);
+    } else {
+        const float *M = xforms[xf].w2o;
+        r.oo = transform_point(M, r.o);
+        r.od = normalize(transform_vector(M, r.d));
+    }
     r.xf = xf;
 }
 
@@ -132,7 +140,7 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.slack0 = 1.5e-5f * (sc.coord_scale + m);
-    set_xform(r, sc.xforms, 0);
+    set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 
 // AABB::intersect decision exactly as bvh.rs:60-131 (true divisions, Interval algebra in
@@ -165,7 +173,7 @@ __device__ __forceinline__ Ival ival_intersect(Ival s, Ival o) {
     r.kind = (r.a <= r.b) ? 1 : 2;
     return r;
 }
-__device__ __noinline__ bool box_exact(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 d,
+__device__ __forceinline__ bool box_exact(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, F3 o, F3 d,
                                        float &tmin, float &tmax) {
     Ival xi = ival_new(mnx, mxx, o.x, d.x);
     Ival yi = ival_new(mny, mxy, o.y, d.y);
@@ -222,8 +230,9 @@ __device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const 
     const float4 *q4 = reinterpret_cast<const float4 *>(pp);
     float4 p0 = q4[0], p1 = q4[1], p2 = q4[2], p3 = q4[3];
     uint32_t meta = __float_as_uint(p3.w);
-    uint32_t type = meta & 3u, xf = (meta >> 2) & 0x3FFFu;
-    if (xf != r.xf) set_xform(r, xforms, xf);
+    uint32_t type = meta & 3u, xf = (meta >> 2) & 0x1FFFu;
+    const bool identity = (meta & PRIM_IDENTITY_XFORM) != 0u;
+    if (xf != r.xf) set_xform(r, xforms, xf, identity);
     F3 position = r.oo, direction = r.od;
     float t;
     bool hit = false;
@@ -278,7 +287,7 @@ __device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const 
     }
     if (!hit) return false;
     F3 osp = position + t * direction;                 // object.rs:214
-    F3 wp = transform_point(xforms[xf].o2w, osp);      // object.rs:216-217
+    F3 wp = identity ? osp : transform_point(xforms[xf].o2w, osp);  // object.rs:216-217
     t_world = dot(wp - r.o, r.d);                      // object.rs:218 / ray.rs:31-33
     return true;
 }
@@ -294,38 +303,22 @@ constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the desce
 // Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
 // out [entry][thread] so a wave's accesses are conflict-free, overflowing to global memory.
 struct Stack {
-    uint32_t *lds_ref;
-    float *lds_t;
-    uint32_t *spill_ref;
-    float *spill_t;
+    uint2 *lds;          // this thread's column
+    uint2 *spill;        // this thread's column of [MAX_TREE_DEPTH - LDS_STACK][threads]
     uint32_t spill_stride;
     int sp;
     __device__ __forceinline__ void push(uint32_t ref, float t) {
-        if (sp < LDS_STACK) {
-            lds_ref[sp * BLOCK] = ref;
-            lds_t[sp * BLOCK] = t;
-        } else {
-            size_t k = (size_t)(sp - LDS_STACK) * spill_stride;
-            spill_ref[k] = ref;
-            spill_t[k] = t;
-        }
+        uint2 e = make_uint2(ref, __float_as_uint(t));
+        if (sp < LDS_STACK) lds[sp * BLOCK] = e;
+        else spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
         sp++;
     }
     // Pops the next entry whose box can still matter; TRAV_DONE when the stack is empty.
     __device__ __forceinline__ uint32_t pop(float limit_plus) {
         while (sp > 0) {
             sp--;
-            uint32_t ref;
-            float t;
-            if (sp < LDS_STACK) {
-                ref = lds_ref[sp * BLOCK];
-                t = lds_t[sp * BLOCK];
-            } else {
-                size_t k = (size_t)(sp - LDS_STACK) * spill_stride;
-                ref = spill_ref[k];
-                t = spill_t[k];
-            }
-            if (!(t > limit_plus)) return ref;
+            uint2 e = (sp < LDS_STACK) ? lds[sp * BLOCK] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            if (!(__uint_as_float(e.y) > limit_plus)) return e.x;
         }
         return TRAV_DONE;
     }
@@ -342,15 +335,19 @@ __device__ __forceinline__ void cswap(float &ta, uint32_t &ra, float &tb, uint32
     rb = rhi;
 }
 
-// One slot of a wide node: box decision + pruning; a rejected slot gets (INF, WIDE_EMPTY).
-__device__ __forceinline__ void wide_slot(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, uint32_t ref,
-                                          const RayCtx &r, float limit_plus, float &t, uint32_t &rr) {
-    bool valid = ref != WIDE_EMPTY;
-    float te;
-    bool hit = box_test(mnx, mny, mnz, mxx, mxy, mxz, r, limit_plus, valid && (ref & LEAF_BIT), true, te);
-    hit = hit && valid;
-    t = hit ? fminf(te, 3.0e38f) : INFINITY;
-    rr = hit ? ref : WIDE_EMPTY;
+// Reciprocal slab test of one box (not for exact_only rays): entry/exit t, `miss` when the
+// intervals are clearly separated, `sure` when they clearly overlap; anything else is
+// within the f32 error of the reference's division form and must be decided by box_exact.
+__device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                          const RayCtx &r, float &tmin, float &tmax, bool &miss, bool &sure) {
+    float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
+    float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
+    float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
+    tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
+    miss = tmin > tmax + delta;
+    sure = tmin <= tmax - delta;
 }
 
 // Traversal state of one lane.  trav_begin() starts a ray, trav_step() advances it by one
@@ -393,12 +390,59 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         const float4 *np = reinterpret_cast<const float4 *>(sc.wnodes + cur);
         float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
         float4 rf4 = np[6];
-        float t0, t1, t2, t3;
-        uint32_t r0, r1, r2, r3;
-        wide_slot(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, __float_as_uint(rf4.x), s.r, s.limit_plus, t0, r0);
-        wide_slot(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, __float_as_uint(rf4.y), s.r, s.limit_plus, t1, r1);
-        wide_slot(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, __float_as_uint(rf4.z), s.r, s.limit_plus, t2, r2);
-        wide_slot(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, __float_as_uint(rf4.w), s.r, s.limit_plus, t3, r3);
+        uint32_t r0 = __float_as_uint(rf4.x), r1 = __float_as_uint(rf4.y), r2 = __float_as_uint(rf4.z),
+                 r3 = __float_as_uint(rf4.w);
+        float t0, t1, t2, t3, x0, x1, x2, x3;  // entry / exit t per slot
+        bool m0, m1, m2, m3, s0, s1, s2, s3;
+        slab_fast(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, s.r, t0, x0, m0, s0);
+        slab_fast(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, s.r, t1, x1, m1, s1);
+        slab_fast(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, s.r, t2, x2, m2, s2);
+        slab_fast(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, s.r, t3, x3, m3, s3);
+        // leaf slots inside the error band (and every slot of an exact_only ray) re-run the
+        // reference's divisions; rare, so it sits behind ONE wave-uniform branch and reloads
+        // the slot's box instead of keeping it live
+        const bool eo = s.r.exact_only;
+        uint32_t need = 0, hits = 0;
+        {
+            bool v0 = r0 != WIDE_EMPTY, v1 = r1 != WIDE_EMPTY, v2 = r2 != WIDE_EMPTY, v3 = r3 != WIDE_EMPTY;
+            if (v0 && (eo || ((r0 & LEAF_BIT) && !m0 && !s0))) need |= 1u;
+            if (v1 && (eo || ((r1 & LEAF_BIT) && !m1 && !s1))) need |= 2u;
+            if (v2 && (eo || ((r2 & LEAF_BIT) && !m2 && !s2))) need |= 4u;
+            if (v3 && (eo || ((r3 & LEAF_BIT) && !m3 && !s3))) need |= 8u;
+            if (v0 && !m0) hits |= 1u;
+            if (v1 && !m1) hits |= 2u;
+            if (v2 && !m2) hits |= 4u;
+            if (v3 && !m3) hits |= 8u;
+        }
+        if (__ballot(need != 0u) != 0ull) {
+#pragma unroll 1
+            for (uint32_t k = 0; k < 4u; k++) {
+                if (need & (1u << k)) {
+                    const float *nb = reinterpret_cast<const float *>(sc.wnodes + cur) + k;
+                    float a, b;
+                    bool h = box_exact(nb[0], nb[4], nb[8], nb[12], nb[16], nb[20], s.r.o, s.r.d, a, b);
+                    hits = h ? (hits | (1u << k)) : (hits & ~(1u << k));
+                    if (k == 0u) { t0 = a; x0 = b; }
+                    if (k == 1u) { t1 = a; x1 = b; }
+                    if (k == 2u) { t2 = a; x2 = b; }
+                    if (k == 3u) { t3 = a; x3 = b; }
+                }
+            }
+        }
+        // pruning: box behind the origin or beyond the best hit
+        const float back = -s.r.slack0, lim = s.limit_plus;
+        bool h0 = (hits & 1u) && !(x0 < back) && !(t0 > lim);
+        bool h1 = (hits & 2u) && !(x1 < back) && !(t1 > lim);
+        bool h2 = (hits & 4u) && !(x2 < back) && !(t2 > lim);
+        bool h3 = (hits & 8u) && !(x3 < back) && !(t3 > lim);
+        t0 = h0 ? fminf(t0, 3.0e38f) : INFINITY;
+        t1 = h1 ? fminf(t1, 3.0e38f) : INFINITY;
+        t2 = h2 ? fminf(t2, 3.0e38f) : INFINITY;
+        t3 = h3 ? fminf(t3, 3.0e38f) : INFINITY;
+        r0 = h0 ? r0 : WIDE_EMPTY;
+        r1 = h1 ? r1 : WIDE_EMPTY;
+        r2 = h2 ? r2 : WIDE_EMPTY;
+        r3 = h3 ? r3 : WIDE_EMPTY;
         // sort the four slots by entry t (rejected slots last): the nearest is continued,
         // the others are pushed farthest first
         cswap(t0, r0, t1, r1);
@@ -598,16 +642,13 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 // ---------------------------------------------------------------- trace_closest
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint32_t lds_ref[LDS_STACK * BLOCK];
-    __shared__ float lds_t[LDS_STACK * BLOCK];
+    __shared__ uint2 lds_stack[LDS_STACK * BLOCK];
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
-    st.lds_ref = lds_ref + threadIdx.x;
-    st.lds_t = lds_t + threadIdx.x;
-    st.spill_ref = fr.spill + gtid;
-    st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
+    st.lds = lds_stack + threadIdx.x;
+    st.spill = reinterpret_cast<uint2 *>(fr.spill) + gtid;
     st.spill_stride = nthreads;
     st.sp = 0;
     Trav s;
@@ -665,7 +706,7 @@ __device__ __forceinline__ PrimView load_prim(const Prim *pp) {
     v.p3 = q4[3];
     uint32_t meta = __float_as_uint(v.p3.w);
     v.type = meta & 3u;
-    v.xf = (meta >> 2) & 0x3FFFu;
+    v.xf = (meta >> 2) & 0x1FFFu;
     v.mat = meta >> 16;
     return v;
 }
@@ -853,15 +894,12 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 // ---------------------------------------------------------------- trace_shadow
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint32_t lds_ref[LDS_STACK * BLOCK];
-    __shared__ float lds_t[LDS_STACK * BLOCK];
+    __shared__ uint2 lds_stack[LDS_STACK * BLOCK];
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
-    st.lds_ref = lds_ref + threadIdx.x;
-    st.lds_t = lds_t + threadIdx.x;
-    st.spill_ref = fr.spill + gtid;
-    st.spill_t = reinterpret_cast<float *>(fr.spill + (size_t)nthreads * (MAX_TREE_DEPTH - LDS_STACK)) + gtid;
+    st.lds = lds_stack + threadIdx.x;
+    st.spill = reinterpret_cast<uint2 *>(fr.spill) + gtid;
     st.spill_stride = nthreads;
     st.sp = 0;
     Trav s;
@@ -896,6 +934,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
                         F3 rd = normalize(-ldir);
                         F3 ro = p + 1e-4f * rd;
                         rd = normalize(rd);
+                        dist = INFINITY;  // any hit at all blocks a directional light
                         init_ray(s.r, sc, ro, rd);
                     } else {
                         // Light::in_shadow (light.rs:81-97)
@@ -913,8 +952,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
             const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
             do {
                 bool active = s.cur != TRAV_DONE;
-                if (directional) wave_step<2, COUNT, REF>(sc, s, st, 0.0f);
-                else wave_step<1, COUNT, REF>(sc, s, st, dist);
+                wave_step<1, COUNT, REF>(sc, s, st, dist);
                 if (active && s.cur == TRAV_DONE) {
                     bool reaches = directional ? !s.any : (s.any && !s.occluded);
                     if (reaches) atomicOr(&fr.link[node].x, 1u << l);

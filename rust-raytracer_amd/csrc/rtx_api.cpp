@@ -454,6 +454,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     ds.n_lights = (uint32_t)fs.lights.size();
     ds.root_ref = fs.root_ref;
     ds.wroot_ref = fs.wide_root_ref;
+    ds.xf0_identity = fs.xf0_identity ? 1u : 0u;
     float scale = 0.0f;
     for (int k = 0; k < 3; k++) {
         ds.root_mn[k] = fs.root_mn[k];
