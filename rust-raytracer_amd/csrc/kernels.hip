@@ -302,13 +302,17 @@ constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the desce
 
 // Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
 // out [entry][thread] so a wave's accesses are conflict-free, overflowing to global memory.
+// The two pointers carry their address spaces so that the LDS path stays ds_write_b64 /
+// ds_read_b64 (with generic pointers the compiler merges both paths into flat accesses).
+typedef __attribute__((address_space(3))) unsigned long long *LdsStackPtr;   // entry = ref | t bits << 32
+typedef __attribute__((address_space(1))) unsigned long long *GlobalStackPtr;
 struct Stack {
-    uint2 *lds;          // this thread's column
-    uint2 *spill;        // this thread's column of [MAX_TREE_DEPTH - LDS_STACK][threads]
+    LdsStackPtr lds;        // this thread's column
+    GlobalStackPtr spill;   // this thread's column of [MAX_TREE_DEPTH - LDS_STACK][threads]
     uint32_t spill_stride;
     int sp;
     __device__ __forceinline__ void push(uint32_t ref, float t) {
-        uint2 e = make_uint2(ref, __float_as_uint(t));
+        unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(t) << 32);
         if (sp < LDS_STACK) lds[sp * BLOCK] = e;
         else spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
         sp++;
@@ -317,8 +321,10 @@ struct Stack {
     __device__ __forceinline__ uint32_t pop(float limit_plus) {
         while (sp > 0) {
             sp--;
-            uint2 e = (sp < LDS_STACK) ? lds[sp * BLOCK] : spill[(size_t)(sp - LDS_STACK) * spill_stride];
-            if (!(__uint_as_float(e.y) > limit_plus)) return e.x;
+            unsigned long long e;
+            if (sp < LDS_STACK) e = lds[sp * BLOCK];
+            else e = spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            if (!(__uint_as_float((uint32_t)(e >> 32)) > limit_plus)) return (uint32_t)e;
         }
         return TRAV_DONE;
     }
@@ -404,15 +410,14 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         const bool eo = s.r.exact_only;
         uint32_t need = 0, hits = 0;
         {
+            // branch-free: (int32)ref < -1  <=>  leaf slot that is not WIDE_EMPTY
             bool v0 = r0 != WIDE_EMPTY, v1 = r1 != WIDE_EMPTY, v2 = r2 != WIDE_EMPTY, v3 = r3 != WIDE_EMPTY;
-            if (v0 && (eo || ((r0 & LEAF_BIT) && !m0 && !s0))) need |= 1u;
-            if (v1 && (eo || ((r1 & LEAF_BIT) && !m1 && !s1))) need |= 2u;
-            if (v2 && (eo || ((r2 & LEAF_BIT) && !m2 && !s2))) need |= 4u;
-            if (v3 && (eo || ((r3 & LEAF_BIT) && !m3 && !s3))) need |= 8u;
-            if (v0 && !m0) hits |= 1u;
-            if (v1 && !m1) hits |= 2u;
-            if (v2 && !m2) hits |= 4u;
-            if (v3 && !m3) hits |= 8u;
+            bool n0 = (eo & v0) | (((int32_t)r0 < -1) & !m0 & !s0);
+            bool n1 = (eo & v1) | (((int32_t)r1 < -1) & !m1 & !s1);
+            bool n2 = (eo & v2) | (((int32_t)r2 < -1) & !m2 & !s2);
+            bool n3 = (eo & v3) | (((int32_t)r3 < -1) & !m3 & !s3);
+            need = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
+            hits = ((v0 & !m0) ? 1u : 0u) | ((v1 & !m1) ? 2u : 0u) | ((v2 & !m2) ? 4u : 0u) | ((v3 & !m3) ? 8u : 0u);
         }
         if (__ballot(need != 0u) != 0ull) {
 #pragma unroll 1
@@ -642,13 +647,13 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 // ---------------------------------------------------------------- trace_closest
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint2 lds_stack[LDS_STACK * BLOCK];
+    __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.spill = reinterpret_cast<uint2 *>(fr.spill) + gtid;
+    st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
+    st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
     st.spill_stride = nthreads;
     st.sp = 0;
     Trav s;
@@ -894,12 +899,12 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 // ---------------------------------------------------------------- trace_shadow
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ uint2 lds_stack[LDS_STACK * BLOCK];
+    __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.spill = reinterpret_cast<uint2 *>(fr.spill) + gtid;
+    st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
+    st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
     st.spill_stride = nthreads;
     st.sp = 0;
     Trav s;
