@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
     ap.add_argument("--cpu-row-stride", type=int, default=2, help="oracle traces every n-th image row")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -60,11 +62,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -103,10 +110,11 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_step = stats[-1].rays
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        cdev = device if args.backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([rays_step], dtype=torch.int64, device=device)
+        rr = torch.tensor([rays_step], dtype=torch.int64, device=cdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_step = int(rr.item())
     if rank != 0:

@@ -59,6 +59,9 @@ def gather_image(local_tiles, width, height, tile, rank, nranks, dist=None):
         flat = torch.cat([flat, torch.zeros(need - flat.numel(), dtype=flat.dtype, device=flat.device)])
     if nranks == 1:
         return assemble(flat.reshape(1, n, tile, tile, 3), width, height, tile, 1)
+    dev = flat.device
+    if dist.get_backend() != "nccl" and dev.type != "cpu":  # rehearsal backends gather through the host
+        flat = flat.cpu()
     out = torch.empty(nranks * need, dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat.contiguous())
-    return assemble(out.reshape(nranks, n, tile, tile, 3), width, height, tile, nranks)
+    return assemble(out.reshape(nranks, n, tile, tile, 3).to(dev), width, height, tile, nranks)
