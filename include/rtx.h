@@ -94,7 +94,7 @@ typedef struct rtx_stats {
     double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches */
     uint32_t closest_launches, shadow_launches;
     uint32_t batches;
-    uint32_t reserved;
+    uint32_t max_ray_records;   /* most node + primitive records visited by one ray (COUNT_VISITS) */
 } rtx_stats;
 
 /* BVH facts after upload (bvh.rs:18-24 logs the same numbers). */

@@ -49,7 +49,7 @@ class Stats(C.Structure):
                 ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64),
                 ("trace_ms", C.c_double), ("closest_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
                 ("closest_launches", C.c_uint32), ("shadow_launches", C.c_uint32),
-                ("batches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("batches", C.c_uint32), ("max_ray_records", C.c_uint32)]
 
     @property
     def rays(self):

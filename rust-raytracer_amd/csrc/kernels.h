@@ -43,11 +43,20 @@ enum {
     CTR_SVISIT_NODES_HI,
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
-    CTR_WORK = 160,         // [8][CTR_WORK_STRIDE] queue heads of the persistent trace kernels:
-    CTR_WORK_STRIDE = 1 + MAX_LIGHTS,  //   word 0 = trace_closest, 1 + l = trace_shadow of light l
-    CTR_WORDS = CTR_WORK + 8 * CTR_WORK_STRIDE
+    CTR_MAX_STEPS,                          // most records visited by a single ray (COUNT)
+    CTR_WORDS = 160
 };
-static_assert(CTR_VISIT_NODES_LO % 2 == 0 && CTR_SVISIT_PRIMS_HI < CTR_WORDS, "64-bit counters must be 8-byte aligned");
+// Queue heads of the persistent trace kernels live in their own buffer (Frame::work): per
+// bounce level WORK_QUEUES queues (0 = trace_closest, 1 + l = trace_shadow of light l), each
+// split into QPARTS sub-queues whose head counters sit on separate 128-byte lines -- one
+// hot counter sustains only ~90 atomics/us, which bounds small frames (multi-GPU shares).
+enum {
+    WORK_QUEUES = 1 + MAX_LIGHTS,
+    QPARTS = 16,
+    QHEAD_STRIDE = 32,  // words
+    WORK_WORDS = 8 * WORK_QUEUES * QPARTS * QHEAD_STRIDE
+};
+static_assert(CTR_VISIT_NODES_LO % 2 == 0 && CTR_MAX_STEPS < CTR_WORDS, "64-bit counters must be 8-byte aligned");
 
 // Wavefront state of one batch of primary samples ("path nodes": one per traced ray).
 struct Frame {
@@ -55,8 +64,9 @@ struct Frame {
     float4 *ray_d;      // xyz direction, w = bits of hit primitive (leaf order)
     uint2 *link;        // x = lit-light mask, y = first bounce child (NO_PRIM: none)
     float4 *color;      // resolved colour of the node
-    uint32_t *shadow_q; // [MAX_LIGHTS][q_cap] node ids waiting for a shadow query
+    uint32_t *shadow_q; // [level][n_lights][q_cap] node ids waiting for a shadow query
     uint32_t *counters; // CTR_WORDS
+    uint32_t *work;     // WORK_WORDS queue heads
     uint32_t *spill;    // traversal-stack overflow, [MAX_TREE_DEPTH-LDS_STACK][threads] of (ref, t)
     uint32_t node_cap, q_cap;
 };

@@ -545,28 +545,54 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #define RTX_REFILL_MIN 16
 #endif
 struct WaveQueue {
-    uint32_t *head;
-    uint32_t count, chunk;
+    uint32_t *heads;
+    uint32_t count, chunk, psize, dyn0, p0, tried;
     uint32_t next, end;
     bool exhausted;
-    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nwaves) {
-        head = h;
+    // Sub-queue p covers [p*psize, (p+1)*psize).  Its first waves_per_part*chunk entries
+    // are dealt statically (wave j of the sub-queue owns chunk j: no atomic at all for
+    // queues that small); the rest is handed out through the sub-queue's head counter.
+    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nwaves, uint32_t wave) {
+        heads = h;
         count = n;
         uint32_t c = n / (nwaves * 4u);
         chunk = c < 64u ? 64u : (c > 256u ? 256u : c);
-        next = end = 0;
+        psize = ((n + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS + 63u) & ~63u;
+        dyn0 = ((nwaves + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS) * chunk;
+        p0 = wave % (uint32_t)QPARTS;
+        tried = 0;
         exhausted = n == 0;
+        uint32_t pb = p0 * psize, j = wave / (uint32_t)QPARTS;
+        uint32_t pe = pb + psize < n ? pb + psize : n;
+        next = pb + j * chunk;
+        end = next + chunk < pe ? next + chunk : pe;
+        if (pb >= n || next >= pe) next = end = 0;
     }
     // Gives every idle lane (ballot `idle`) its queue index; returns false for lanes left empty.
     __device__ __forceinline__ bool take(unsigned long long idle, bool lane_idle, uint32_t &index) {
-        if (next >= end) {
-            next = wave_fetch(head, chunk);
-            end = next + chunk < count ? next + chunk : count;
-            if (next >= count) {
+        while (next >= end) {  // own run used up: this sub-queue's counter, then the others'
+            if (tried >= (uint32_t)QPARTS) {
                 exhausted = true;
-                next = end = count;
+                next = end = 0;
                 return false;
             }
+            uint32_t p = (p0 + tried) % (uint32_t)QPARTS;
+            uint32_t pb = p * psize;
+            uint32_t pe = pb + psize < count ? pb + psize : count;
+            uint32_t dyn = (pb < count && pe - pb > dyn0) ? pe - pb - dyn0 : 0u;
+            uint32_t *hp = heads + p * (uint32_t)QHEAD_STRIDE;
+            uint32_t b = dyn;
+            if (dyn != 0u) {
+                // look before taking: an exhausted counter costs a load, not a serialised atomic
+                uint32_t peek = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (peek < dyn) b = wave_fetch(hp, chunk);
+            }
+            if (b >= dyn) {
+                tried++;
+                continue;
+            }
+            next = pb + dyn0 + b;
+            end = next + chunk < pe ? next + chunk : pe;
         }
         uint32_t avail = end - next, nidle = (uint32_t)__popcll(idle);
         uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
@@ -660,8 +686,10 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
     s.cur = TRAV_DONE;
     s.nodes = s.prims = 0;
     uint32_t node = 0;
+    uint32_t ray_steps = 0, max_steps = 0;  // COUNT: records visited by the current ray / the longest ray
     WaveQueue wq;
-    wq.init(fr.counters + CTR_WORK + level * CTR_WORK_STRIDE, fr.counters[CTR_LEVEL_COUNT + level], nthreads / 64u);
+    wq.init(fr.work + (size_t)(level * WORK_QUEUES) * (QPARTS * QHEAD_STRIDE), fr.counters[CTR_LEVEL_COUNT + level],
+            nthreads / 64u, gtid / 64u);
     for (;;) {
         unsigned long long idle = __ballot(s.cur == TRAV_DONE);
         uint32_t nidle = (uint32_t)__popcll(idle);
@@ -687,14 +715,23 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
         const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
         do {
             bool active = s.cur != TRAV_DONE;
+            uint32_t before = s.nodes + s.prims;
             wave_step<0, COUNT, REF>(sc, s, st, 0.0f);
+            if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 fr.ray_o[node].w = s.any ? s.t : 0.0f;
                 fr.ray_d[node].w = __uint_as_float(s.prim);
+                if (COUNT) {
+                    max_steps = ray_steps > max_steps ? ray_steps : max_steps;
+                    ray_steps = 0;
+                }
             }
         } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
     }
-    if (COUNT) add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
+    if (COUNT) {
+        add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
+        atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
+    }
 }
 
 // ---------------------------------------------------------------- object.rs helpers for shading
@@ -851,7 +888,7 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
                 unsigned long long mask = __ballot(mine);
                 if (mine) {
                     uint32_t slot = run + (uint32_t)__popcll(mask & lt_mask);
-                    if (slot < fr.q_cap) fr.shadow_q[(size_t)l * fr.q_cap + slot] = base + i0 + r * BLOCK + threadIdx.x;
+                    if (slot < fr.q_cap) fr.shadow_q[((size_t)level * nl + l) * fr.q_cap + slot] = base + i0 + r * BLOCK + threadIdx.x;
                     else fr.counters[CTR_OVERFLOW] = 1;
                 }
                 run += (uint32_t)__popcll(mask);
@@ -911,18 +948,19 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
     s.cur = TRAV_DONE;
     s.nodes = s.prims = 0;
     uint32_t node = 0;
+    uint32_t ray_steps = 0, max_steps = 0;
     float dist = 0.0f;
     for (uint32_t l = 0; l < sc.n_lights; l++) {
         const LightRec &L = sc.lights[l];
         if (L.type == LIGHT_AMBIENT) continue;
         uint32_t count = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
         if (count > fr.q_cap) count = fr.q_cap;
-        const uint32_t *q = fr.shadow_q + (size_t)l * fr.q_cap;
+        const uint32_t *q = fr.shadow_q + ((size_t)level * sc.n_lights + l) * fr.q_cap;
         const F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
         const F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
         const bool directional = L.type == 2u;
         WaveQueue wq;
-        wq.init(fr.counters + CTR_WORK + level * CTR_WORK_STRIDE + 1 + l, count, nthreads / 64u);
+        wq.init(fr.work + (size_t)(level * WORK_QUEUES + 1 + l) * (QPARTS * QHEAD_STRIDE), count, nthreads / 64u, gtid / 64u);
         for (;;) {
             unsigned long long idle = __ballot(s.cur == TRAV_DONE);
             uint32_t nidle = (uint32_t)__popcll(idle);
@@ -957,15 +995,24 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
             const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
             do {
                 bool active = s.cur != TRAV_DONE;
+                uint32_t before = s.nodes + s.prims;
                 wave_step<1, COUNT, REF>(sc, s, st, dist);
+                if (COUNT) ray_steps += s.nodes + s.prims - before;
                 if (active && s.cur == TRAV_DONE) {
                     bool reaches = directional ? !s.any : (s.any && !s.occluded);
                     if (reaches) atomicOr(&fr.link[node].x, 1u << l);
+                    if (COUNT) {
+                        max_steps = ray_steps > max_steps ? ray_steps : max_steps;
+                        ray_steps = 0;
+                    }
                 }
             } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
         }
     }
-    if (COUNT) add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
+    if (COUNT) {
+        add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
+        atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
+    }
 }
 
 // ---------------------------------------------------------------- resolve

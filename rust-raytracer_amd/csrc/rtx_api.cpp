@@ -28,6 +28,10 @@ double now_s() {
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // trace_shadow(k) runs here, beside trace_closest(k+1)
+    std::vector<hipEvent_t> order;       // ordering events between the two streams (no timing)
+    uint32_t *spill_side = nullptr;      // traversal-stack overflow of the kernels on `side`
+    uint32_t frame_levels = 0;
     std::string err;
     int persistent_blocks = 1024;
     // scene
@@ -141,13 +145,14 @@ int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
         c->err = "batch exceeds 2^32 path nodes";
         return RTX_ERR_CAPACITY;
     }
-    if (c->fr.ray_o && node_cap <= c->node_cap && q_cap <= c->q_cap && nl <= c->frame_lights) {
+    if (c->fr.ray_o && node_cap <= c->node_cap && q_cap <= c->q_cap && nl <= c->frame_lights && levels <= c->frame_levels) {
         c->fr.node_cap = (uint32_t)c->node_cap;
         c->fr.q_cap = (uint32_t)c->q_cap;
         return RTX_OK;
     }
     free_all(c->frame_allocs);
     c->fr = Frame{};
+    c->spill_side = nullptr;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
         if (e == hipSuccess) c->frame_allocs.push_back(*p);
@@ -157,14 +162,17 @@ int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&c->fr.ray_d, node_cap * sizeof(float4)));
     HIP_TRY(c, alloc((void **)&c->fr.link, node_cap * sizeof(uint2)));
     HIP_TRY(c, alloc((void **)&c->fr.color, node_cap * sizeof(float4)));
-    HIP_TRY(c, alloc((void **)&c->fr.shadow_q, (size_t)nl * q_cap * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&c->fr.shadow_q, (size_t)levels * nl * q_cap * sizeof(uint32_t)));
     HIP_TRY(c, alloc((void **)&c->fr.counters, CTR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&c->fr.work, WORK_WORDS * sizeof(uint32_t)));
     size_t threads = (size_t)c->persistent_blocks * 256;
     HIP_TRY(c, alloc((void **)&c->fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
+    HIP_TRY(c, alloc((void **)&c->spill_side, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
     c->node_cap = node_cap;
     c->q_cap = q_cap;
     c->cap0 = n0;
     c->frame_lights = nl;
+    c->frame_levels = levels;
     c->fr.node_cap = (uint32_t)node_cap;
     c->fr.q_cap = (uint32_t)q_cap;
     return RTX_OK;
@@ -210,19 +218,39 @@ struct Batch {
 };
 
 // Runs the wavefront pipeline of one batch whose level-0 rays are already in the frame.
-// Records 4 events per level starting at events[ev0] when timing is on.
-void run_levels(rtx_ctx *c, const LaunchCfg &lc, uint32_t levels, bool timing, size_t ev0) {
+// Per level: trace_closest -> shade_forward on the main stream; trace_shadow of that level
+// goes to the side stream and runs beside the NEXT level's trace_closest (they touch
+// disjoint path nodes and per-level queues), so the tail of one persistent kernel -- a few
+// long rays -- is filled by the other instead of idling the GPU eight times per frame.
+// Records 4 timing events per level starting at events[ev0] when timing is on.
+int run_levels(rtx_ctx *c, const LaunchCfg &lc, uint32_t levels, bool timing, size_t ev0) {
+    while (c->order.size() < (size_t)levels + 1) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->order.push_back(e);
+    }
+    LaunchCfg ls = lc;
+    ls.stream = c->side;
+    Frame fs = c->fr;
+    fs.spill = c->spill_side;
     for (uint32_t k = 0; k < levels; k++) {
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], lc.stream);
         launch_trace_closest(c->ds, c->fr, k, lc);
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], lc.stream);
         launch_shade_forward(c->ds, c->fr, k, levels, lc);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], lc.stream);
-        launch_trace_shadow(c->ds, c->fr, k, lc);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], lc.stream);
+        HIP_TRY(c, hipEventRecord(c->order[k], lc.stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->order[k], 0));
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], c->side);
+        launch_trace_shadow(c->ds, fs, k, ls);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], c->side);
+    }
+    if (levels) {
+        HIP_TRY(c, hipEventRecord(c->order[levels], c->side));
+        HIP_TRY(c, hipStreamWaitEvent(lc.stream, c->order[levels], 0));
     }
     for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, c->fr, (uint32_t)k, lc);
     if (levels == 0) launch_resolve(c->ds, c->fr, 0, lc);
+    return RTX_OK;
 }
 
 int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part, uint32_t flags,
@@ -248,7 +276,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     }
     uint32_t levels = bounces;
     uint32_t K = c->max_bounce;
-    uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 56 + geo_last(K, std::max(levels, 1u)) * 4 * std::max(c->ds.n_lights, 1u);
+    uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 56 + geo_last(K, std::max(levels, 1u)) * 4 * std::max(c->ds.n_lights, 1u) * std::max(levels, 1u);
     uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / per_sample, 4096);
     uint64_t total = pt.npix * spp;
     std::vector<Batch> batches;
@@ -303,8 +331,10 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         info.tiles_y = pt.tiles_y;
         info.max_levels = levels;
         HIP_TRY(c, hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream));
         launch_raygen(c->ds, c->fr, info, lc);
-        run_levels(c, lc, levels, timing, ev_per_batch * bi);
+        rc = run_levels(c, lc, levels, timing, ev_per_batch * bi);
+        if (rc != RTX_OK) return rc;
         launch_accumulate(c->ds, c->fr, info, c->sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
         HIP_TRY(c, hipMemcpyAsync(c->h_counters + bi * CTR_WORDS, c->fr.counters, CTR_WORDS * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, c->stream));
@@ -341,6 +371,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->closest_prims += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
             stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
             stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
+            stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
             for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
                 size_t e = ev_per_batch * bi + 4 * k;
@@ -385,6 +416,13 @@ int rtx_init(int device, rtx_ctx **out) {
         delete c;
         return RTX_ERR_HIP;
     }
+    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return RTX_ERR_HIP;
+    }
     c->persistent_blocks = query_persistent_blocks(device);
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
         long v = std::atol(mb);
@@ -405,6 +443,8 @@ void rtx_destroy(rtx_ctx *c) {
     if (c->tiles_f32) (void)hipFree(c->tiles_f32);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto e : c->events) (void)hipEventDestroy(e);
+    for (auto e : c->order) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->side);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -600,6 +640,7 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
         info.tiles_y = pt.tiles_y;
         info.max_levels = 1;
         (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream);
         launch_raygen(c->ds, c->fr, info, lc);
         launch_trace_closest(c->ds, c->fr, 0, lc);
         launch_export_hits(c->ds, c->fr, n, d_obj, d_t, lc);
@@ -651,9 +692,10 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - i0);
         hipError_t e = hipMemcpyAsync(d_rays, org_dir + i0 * 6, (size_t)m * 24, hipMemcpyHostToDevice, c->stream);
         (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream);
         launch_load_rays(c->fr, d_rays, m, lc);
         if (out_rgb) {
-            run_levels(c, lc, levels, false, 0);
+            if (run_levels(c, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
             launch_export_colors(c->fr, m, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
         } else {
