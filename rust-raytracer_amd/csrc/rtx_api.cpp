@@ -25,13 +25,24 @@ double now_s() {
 }
 }  // namespace
 
+// One in-flight batch: its wavefront buffers and the two streams its kernels run on.
+struct Pipe {
+    Frame fr{};
+    std::vector<void *> allocs;
+    uint64_t node_cap = 0, q_cap = 0;
+    uint32_t lights = 0, levels = 0;
+    hipStream_t main = nullptr;
+    hipStream_t side = nullptr;       // trace_shadow(k) runs here, beside trace_closest(k+1)
+    uint32_t *spill_side = nullptr;   // traversal-stack overflow of the kernels on `side`
+    std::vector<hipEvent_t> order;    // ordering events between the two streams (no timing)
+};
+
 struct rtx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;          // trace_shadow(k) runs here, beside trace_closest(k+1)
-    std::vector<hipEvent_t> order;       // ordering events between the two streams (no timing)
-    uint32_t *spill_side = nullptr;      // traversal-stack overflow of the kernels on `side`
-    uint32_t frame_levels = 0;
+    hipStream_t stream = nullptr;     // = pipes[0].main, the stream rtx_stream() hands out
+    std::vector<Pipe> pipes;          // batches of one render are dealt round-robin over the pipes
+    std::vector<hipEvent_t> chain;    // per batch: "accumulated and counters copied" (ordering only)
+    hipEvent_t start_ev = nullptr;
     std::string err;
     int persistent_blocks = 1024;
     // scene
@@ -41,11 +52,7 @@ struct rtx_ctx {
     std::vector<uint32_t> leaf_order, preorder_sizes;
     rtx_bvh_info info{};
     uint32_t max_bounce = 0;
-    // wavefront state
-    Frame fr{};
-    std::vector<void *> frame_allocs;
-    uint64_t cap0 = 0, node_cap = 0, q_cap = 0;
-    uint32_t frame_lights = 0;
+    // per-render state
     float4 *sum = nullptr;
     uint8_t *tiles = nullptr;
     float *tiles_f32 = nullptr;
@@ -135,8 +142,8 @@ uint64_t geo_last(uint32_t K, uint32_t levels) {
     return std::max<uint64_t>(g, 1);
 }
 
-// Makes sure the wavefront buffers hold `n0` primary samples traced `levels` deep.
-int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
+// Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep.
+int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     uint32_t K = c->max_bounce;
     uint64_t node_cap = n0 * geo_sum(K, levels);
     uint64_t q_cap = n0 * geo_last(K, levels);
@@ -145,36 +152,44 @@ int ensure_frame(rtx_ctx *c, uint64_t n0, uint32_t levels) {
         c->err = "batch exceeds 2^32 path nodes";
         return RTX_ERR_CAPACITY;
     }
-    if (c->fr.ray_o && node_cap <= c->node_cap && q_cap <= c->q_cap && nl <= c->frame_lights && levels <= c->frame_levels) {
-        c->fr.node_cap = (uint32_t)c->node_cap;
-        c->fr.q_cap = (uint32_t)c->q_cap;
+    if (pp.fr.ray_o && node_cap <= pp.node_cap && q_cap <= pp.q_cap && nl <= pp.lights && levels <= pp.levels) {
+        pp.fr.node_cap = (uint32_t)pp.node_cap;
+        pp.fr.q_cap = (uint32_t)pp.q_cap;
         return RTX_OK;
     }
-    free_all(c->frame_allocs);
-    c->fr = Frame{};
-    c->spill_side = nullptr;
+    HIP_TRY(c, hipStreamSynchronize(pp.main));
+    HIP_TRY(c, hipStreamSynchronize(pp.side));
+    free_all(pp.allocs);
+    pp.fr = Frame{};
+    pp.spill_side = nullptr;
+    pp.node_cap = pp.q_cap = 0;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
-        if (e == hipSuccess) c->frame_allocs.push_back(*p);
+        if (e == hipSuccess) pp.allocs.push_back(*p);
         return e;
     };
-    HIP_TRY(c, alloc((void **)&c->fr.ray_o, node_cap * sizeof(float4)));
-    HIP_TRY(c, alloc((void **)&c->fr.ray_d, node_cap * sizeof(float4)));
-    HIP_TRY(c, alloc((void **)&c->fr.link, node_cap * sizeof(uint2)));
-    HIP_TRY(c, alloc((void **)&c->fr.color, node_cap * sizeof(float4)));
-    HIP_TRY(c, alloc((void **)&c->fr.shadow_q, (size_t)levels * nl * q_cap * sizeof(uint32_t)));
-    HIP_TRY(c, alloc((void **)&c->fr.counters, CTR_WORDS * sizeof(uint32_t)));
-    HIP_TRY(c, alloc((void **)&c->fr.work, WORK_WORDS * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&pp.fr.ray_o, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&pp.fr.ray_d, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&pp.fr.link, node_cap * sizeof(uint2)));
+    HIP_TRY(c, alloc((void **)&pp.fr.color, node_cap * sizeof(float4)));
+    HIP_TRY(c, alloc((void **)&pp.fr.shadow_q, (size_t)levels * nl * q_cap * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&pp.fr.counters, CTR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
     size_t threads = (size_t)c->persistent_blocks * 256;
-    HIP_TRY(c, alloc((void **)&c->fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
-    HIP_TRY(c, alloc((void **)&c->spill_side, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
-    c->node_cap = node_cap;
-    c->q_cap = q_cap;
-    c->cap0 = n0;
-    c->frame_lights = nl;
-    c->frame_levels = levels;
-    c->fr.node_cap = (uint32_t)node_cap;
-    c->fr.q_cap = (uint32_t)q_cap;
+    HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
+    HIP_TRY(c, alloc((void **)&pp.spill_side, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
+    pp.node_cap = node_cap;
+    pp.q_cap = q_cap;
+    pp.lights = nl;
+    pp.levels = levels;
+    pp.fr.node_cap = (uint32_t)node_cap;
+    pp.fr.q_cap = (uint32_t)q_cap;
+    return RTX_OK;
+}
+
+int reset_counters(rtx_ctx *c, Pipe &pp) {
+    HIP_TRY(c, hipMemsetAsync(pp.fr.counters, 0, CTR_WORDS * sizeof(uint32_t), pp.main));
+    HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, WORK_WORDS * sizeof(uint32_t), pp.main));
     return RTX_OK;
 }
 
@@ -213,6 +228,15 @@ int ensure_events(rtx_ctx *c, size_t n) {
     return RTX_OK;
 }
 
+int ensure_chain(rtx_ctx *c, size_t n) {
+    while (c->chain.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chain.push_back(e);
+    }
+    return RTX_OK;
+}
+
 struct Batch {
     uint32_t q0, npix, s0, ns;
 };
@@ -223,33 +247,34 @@ struct Batch {
 // disjoint path nodes and per-level queues), so the tail of one persistent kernel -- a few
 // long rays -- is filled by the other instead of idling the GPU eight times per frame.
 // Records 4 timing events per level starting at events[ev0] when timing is on.
-int run_levels(rtx_ctx *c, const LaunchCfg &lc, uint32_t levels, bool timing, size_t ev0) {
-    while (c->order.size() < (size_t)levels + 1) {
+int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
+    while (pp.order.size() < (size_t)levels + 1) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->order.push_back(e);
+        pp.order.push_back(e);
     }
+    lc.stream = pp.main;
     LaunchCfg ls = lc;
-    ls.stream = c->side;
-    Frame fs = c->fr;
-    fs.spill = c->spill_side;
+    ls.stream = pp.side;
+    Frame fs = pp.fr;
+    fs.spill = pp.spill_side;
     for (uint32_t k = 0; k < levels; k++) {
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], lc.stream);
-        launch_trace_closest(c->ds, c->fr, k, lc);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], lc.stream);
-        launch_shade_forward(c->ds, c->fr, k, levels, lc);
-        HIP_TRY(c, hipEventRecord(c->order[k], lc.stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->side, c->order[k], 0));
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], c->side);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], pp.main);
+        launch_trace_closest(c->ds, pp.fr, k, lc);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], pp.main);
+        launch_shade_forward(c->ds, pp.fr, k, levels, lc);
+        HIP_TRY(c, hipEventRecord(pp.order[k], pp.main));
+        HIP_TRY(c, hipStreamWaitEvent(pp.side, pp.order[k], 0));
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], pp.side);
         launch_trace_shadow(c->ds, fs, k, ls);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], c->side);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], pp.side);
     }
     if (levels) {
-        HIP_TRY(c, hipEventRecord(c->order[levels], c->side));
-        HIP_TRY(c, hipStreamWaitEvent(lc.stream, c->order[levels], 0));
+        HIP_TRY(c, hipEventRecord(pp.order[levels], pp.side));
+        HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels], 0));
     }
-    for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, c->fr, (uint32_t)k, lc);
-    if (levels == 0) launch_resolve(c->ds, c->fr, 0, lc);
+    for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
+    if (levels == 0) launch_resolve(c->ds, pp.fr, 0, lc);
     return RTX_OK;
 }
 
@@ -277,27 +302,40 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     uint32_t levels = bounces;
     uint32_t K = c->max_bounce;
     uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 56 + geo_last(K, std::max(levels, 1u)) * 4 * std::max(c->ds.n_lights, 1u) * std::max(levels, 1u);
-    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / per_sample, 4096);
+    // Batches: the frame is cut into at least `P` independent pieces (by sample, else by pixel
+    // range) that run concurrently, one per pipe, so that the serial tail of every persistent
+    // kernel -- one ray can visit 500+ records against a mean of 9 -- overlaps another
+    // piece's bulk instead of idling the GPU.  The node budget is shared between the pipes.
+    const size_t P = c->pipes.size();
+    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / P / per_sample, 4096);
     uint64_t total = pt.npix * spp;
+    const uint32_t want = total >= (1u << 20) ? (uint32_t)P : 1u;
     std::vector<Batch> batches;
-    if (total <= cap0) {
-        batches.push_back(Batch{0, (uint32_t)pt.npix, 0, spp});
-    } else if (pt.npix <= cap0) {
-        uint32_t nsc = (uint32_t)(cap0 / pt.npix);
+    if (pt.npix <= cap0 && spp >= want) {
+        uint32_t nsc = (uint32_t)std::min<uint64_t>(cap0 / std::max<uint64_t>(pt.npix, 1), (spp + want - 1) / want);
+        nsc = std::max(nsc, 1u);
         for (uint32_t s0 = 0; s0 < spp; s0 += nsc) batches.push_back(Batch{0, (uint32_t)pt.npix, s0, std::min(nsc, spp - s0)});
     } else {
-        uint64_t chunk = cap0 & ~63ull;
+        uint64_t parts = std::max<uint64_t>((pt.npix + cap0 - 1) / cap0, (want + spp - 1) / spp);
+        uint64_t chunk = (((pt.npix + parts - 1) / parts) + 63) & ~63ull;
+        chunk = std::max<uint64_t>(std::min<uint64_t>(chunk, cap0 & ~63ull), 64);
         for (uint64_t q0 = 0; q0 < pt.npix; q0 += chunk)
             for (uint32_t s0 = 0; s0 < spp; s0++)
                 batches.push_back(Batch{(uint32_t)q0, (uint32_t)std::min<uint64_t>(chunk, pt.npix - q0), s0, 1});
     }
+    if (batches.empty()) batches.push_back(Batch{0, 0, 0, spp});
     uint64_t n0max = 0;
     for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
-    rc = ensure_frame(c, n0max, std::max(levels, 1u));
-    if (rc != RTX_OK) return rc;
+    const size_t used = std::min(P, batches.size());
+    for (size_t p = 0; p < used; p++) {
+        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
+        if (rc != RTX_OK) return rc;
+    }
     rc = ensure_pixels(c, pt.npix, want_f32);
     if (rc != RTX_OK) return rc;
     rc = ensure_counter_slots(c, (uint32_t)batches.size());
+    if (rc != RTX_OK) return rc;
+    rc = ensure_chain(c, batches.size());
     if (rc != RTX_OK) return rc;
     bool timing = stats != nullptr;
     size_t ev_per_batch = 4 * (size_t)levels;
@@ -313,8 +351,11 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         t0 = now_s();
     }
+    HIP_TRY(c, hipEventRecord(c->start_ev, c->stream));
     for (size_t bi = 0; bi < batches.size(); bi++) {
         const Batch &b = batches[bi];
+        Pipe &pp = c->pipes[bi % P];
+        lc.stream = pp.main;
         BatchInfo info{};
         info.q0 = b.q0;
         info.npix = b.npix;
@@ -330,15 +371,20 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         info.tiles_x = pt.tiles_x;
         info.tiles_y = pt.tiles_y;
         info.max_levels = levels;
-        HIP_TRY(c, hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream));
-        launch_raygen(c->ds, c->fr, info, lc);
-        rc = run_levels(c, lc, levels, timing, ev_per_batch * bi);
+        if (bi < P && bi != 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->start_ev, 0));  // after whatever preceded this render
+        rc = reset_counters(c, pp);
         if (rc != RTX_OK) return rc;
-        launch_accumulate(c->ds, c->fr, info, c->sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
-        HIP_TRY(c, hipMemcpyAsync(c->h_counters + bi * CTR_WORDS, c->fr.counters, CTR_WORDS * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, c->stream));
+        launch_raygen(c->ds, pp.fr, info, lc);
+        rc = run_levels(c, pp, lc, levels, timing, ev_per_batch * bi);
+        if (rc != RTX_OK) return rc;
+        // sums are folded in sample order (world.rs:54-61): accumulate follows the previous batch's
+        if (bi > 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->chain[bi - 1], 0));
+        launch_accumulate(c->ds, pp.fr, info, c->sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
+        HIP_TRY(c, hipMemcpyAsync(c->h_counters + bi * CTR_WORDS, pp.fr.counters, CTR_WORDS * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, pp.main));
+        HIP_TRY(c, hipEventRecord(c->chain[bi], pp.main));
     }
+    if ((batches.size() - 1) % P != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->chain[batches.size() - 1], 0));
     HIP_TRY(c, hipGetLastError());
     if (!stats && d_tiles_out) return RTX_OK;  // asynchronous device render
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -410,19 +456,20 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     rtx_ctx *c = new rtx_ctx();
     c->device = device;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    int n_pipes = 2;
+    if (const char *np = std::getenv("RTX_PIPES")) n_pipes = std::min(4, std::max(1, std::atoi(np)));
+    c->pipes.resize((size_t)n_pipes);
+    e = hipEventCreateWithFlags(&c->start_ev, hipEventDisableTiming);
+    for (auto &pp : c->pipes) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.main, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.side, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) {
         g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-        delete c;
+        rtx_destroy(c);
         return RTX_ERR_HIP;
     }
-    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        return RTX_ERR_HIP;
-    }
+    c->stream = c->pipes[0].main;
     c->persistent_blocks = query_persistent_blocks(device);
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
         long v = std::atol(mb);
@@ -435,17 +482,24 @@ int rtx_init(int device, rtx_ctx **out) {
 void rtx_destroy(rtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (auto &pp : c->pipes) {
+        if (pp.main) (void)hipStreamSynchronize(pp.main);
+        if (pp.side) (void)hipStreamSynchronize(pp.side);
+    }
     free_all(c->scene_allocs);
-    free_all(c->frame_allocs);
+    for (auto &pp : c->pipes) {
+        free_all(pp.allocs);
+        for (auto e : pp.order) (void)hipEventDestroy(e);
+        if (pp.main) (void)hipStreamDestroy(pp.main);
+        if (pp.side) (void)hipStreamDestroy(pp.side);
+    }
     if (c->sum) (void)hipFree(c->sum);
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->tiles_f32) (void)hipFree(c->tiles_f32);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto e : c->events) (void)hipEventDestroy(e);
-    for (auto e : c->order) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->side);
-    (void)hipStreamDestroy(c->stream);
+    for (auto e : c->chain) (void)hipEventDestroy(e);
+    if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     delete c;
 }
 
@@ -612,7 +666,8 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
     int rc = make_partition(c, nullptr, pt);
     if (rc != RTX_OK) return rc;
     uint64_t chunk = std::min<uint64_t>(pt.npix, 1ull << 24);
-    rc = ensure_frame(c, chunk, 1);
+    Pipe &pp = c->pipes[0];
+    rc = ensure_frame(c, pp, chunk, 1);
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
     uint32_t *d_obj = nullptr;
@@ -639,11 +694,10 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
         info.tiles_x = pt.tiles_x;
         info.tiles_y = pt.tiles_y;
         info.max_levels = 1;
-        (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
-        (void)hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream);
-        launch_raygen(c->ds, c->fr, info, lc);
-        launch_trace_closest(c->ds, c->fr, 0, lc);
-        launch_export_hits(c->ds, c->fr, n, d_obj, d_t, lc);
+        (void)reset_counters(c, pp);
+        launch_raygen(c->ds, pp.fr, info, lc);
+        launch_trace_closest(c->ds, pp.fr, 0, lc);
+        launch_export_hits(c->ds, pp.fr, n, d_obj, d_t, lc);
         hipError_t e = hipMemcpyAsync(h_obj.data(), d_obj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_t.data(), d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -679,7 +733,8 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t levels = out_rgb ? depth : 1;
     uint64_t chunk = std::min<uint64_t>(n, 1ull << 22);
-    int rc = ensure_frame(c, chunk, std::max(levels, 1u));
+    Pipe &pp = c->pipes[0];
+    int rc = ensure_frame(c, pp, chunk, std::max(levels, 1u));
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
     float *d_rays = nullptr, *d_f = nullptr;
@@ -691,16 +746,15 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
     for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
         uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - i0);
         hipError_t e = hipMemcpyAsync(d_rays, org_dir + i0 * 6, (size_t)m * 24, hipMemcpyHostToDevice, c->stream);
-        (void)hipMemsetAsync(c->fr.counters, 0, CTR_WORDS * sizeof(uint32_t), c->stream);
-        (void)hipMemsetAsync(c->fr.work, 0, WORK_WORDS * sizeof(uint32_t), c->stream);
-        launch_load_rays(c->fr, d_rays, m, lc);
+        (void)reset_counters(c, pp);
+        launch_load_rays(pp.fr, d_rays, m, lc);
         if (out_rgb) {
-            if (run_levels(c, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
-            launch_export_colors(c->fr, m, d_f, lc);
+            if (run_levels(c, pp, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
+            launch_export_colors(pp.fr, m, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
         } else {
-            launch_trace_closest(c->ds, c->fr, 0, lc);
-            launch_export_hits(c->ds, c->fr, m, d_obj, d_f, lc);
+            launch_trace_closest(c->ds, pp.fr, 0, lc);
+            launch_export_hits(c->ds, pp.fr, m, d_obj, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_obj + i0, d_obj, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(out_t + i0, d_f, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);
         }

@@ -67,17 +67,17 @@ def test_config3_scan_2p37M_image(rt, orc, gpu):
 
 
 def test_config3_headline_16spp_batching(rt, gpu, monkeypatch):
-    """The headline frame (1024^2, 16 spp) in one batch and in forced sample chunks."""
+    """The headline frame (1024^2, 16 spp) in its default batches (one per pipe) and in forced smaller chunks."""
     s = rt.HostScene("scan", 1024, 0)
     gpu.upload(s)
     ref, st = gpu.render(spp=16, bounces=4, seed=1)
-    assert st.batches == 1 and st.primary_rays == 16 * 1024 * 1024
+    assert st.batches <= 4 and st.primary_rays == 16 * 1024 * 1024
     monkeypatch.setenv("RTX_NODE_BUDGET_MB", "2048")
     c2 = rt.Context(0)
     try:
         c2.upload(s)
         img, st2 = c2.render(spp=16, bounces=4, seed=1)
-        assert st2.batches > 1
+        assert st2.batches > st.batches
         assert np.array_equal(img, ref) and st2.rays == st.rays
     finally:
         c2.close()
