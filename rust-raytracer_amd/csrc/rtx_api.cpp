@@ -61,6 +61,7 @@ struct rtx_ctx {
     uint32_t h_counter_slots = 0;
     std::vector<hipEvent_t> events;
     uint64_t node_budget_bytes = 32ull << 30;
+    uint64_t overlap_below = 12ull << 20;  // renders with fewer primary samples use the pipes concurrently
 };
 
 namespace {
@@ -242,35 +243,38 @@ struct Batch {
 };
 
 // Runs the wavefront pipeline of one batch whose level-0 rays are already in the frame.
-// Per level: trace_closest -> shade_forward on the main stream; trace_shadow of that level
-// goes to the side stream and runs beside the NEXT level's trace_closest (they touch
+// Per level: trace_closest -> shade_forward -> trace_shadow.  With `overlap`, trace_shadow of
+// a level goes to the side stream and runs beside the NEXT level's trace_closest (they touch
 // disjoint path nodes and per-level queues), so the tail of one persistent kernel -- a few
 // long rays -- is filled by the other instead of idling the GPU eight times per frame.
 // Records 4 timing events per level starting at events[ev0] when timing is on.
-int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
+int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0, bool overlap) {
     while (pp.order.size() < (size_t)levels + 1) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pp.order.push_back(e);
     }
     lc.stream = pp.main;
+    hipStream_t side = overlap ? pp.side : pp.main;
     LaunchCfg ls = lc;
-    ls.stream = pp.side;
+    ls.stream = side;
     Frame fs = pp.fr;
-    fs.spill = pp.spill_side;
+    if (overlap) fs.spill = pp.spill_side;
     for (uint32_t k = 0; k < levels; k++) {
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], pp.main);
         launch_trace_closest(c->ds, pp.fr, k, lc);
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], pp.main);
         launch_shade_forward(c->ds, pp.fr, k, levels, lc);
-        HIP_TRY(c, hipEventRecord(pp.order[k], pp.main));
-        HIP_TRY(c, hipStreamWaitEvent(pp.side, pp.order[k], 0));
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], pp.side);
+        if (overlap) {
+            HIP_TRY(c, hipEventRecord(pp.order[k], pp.main));
+            HIP_TRY(c, hipStreamWaitEvent(side, pp.order[k], 0));
+        }
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], side);
         launch_trace_shadow(c->ds, fs, k, ls);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], pp.side);
+        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], side);
     }
-    if (levels) {
-        HIP_TRY(c, hipEventRecord(pp.order[levels], pp.side));
+    if (levels && overlap) {
+        HIP_TRY(c, hipEventRecord(pp.order[levels], side));
         HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels], 0));
     }
     for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
@@ -306,9 +310,14 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     // range) that run concurrently, one per pipe, so that the serial tail of every persistent
     // kernel -- one ray can visit 500+ records against a mean of 9 -- overlaps another
     // piece's bulk instead of idling the GPU.  The node budget is shared between the pipes.
-    const size_t P = c->pipes.size();
-    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / P / per_sample, 4096);
+    // A launch ends with its longest ray (~0.1-0.5 ms alone on the GPU), which is noise for a
+    // 16 M-sample frame but most of the time for a small share of one (multi-GPU tiles): small
+    // renders run concurrently (pipes + side stream), big ones serially -- which also keeps
+    // the per-kernel HIP-event times of the headline bench free of queueing behind another kernel.
     uint64_t total = pt.npix * spp;
+    bool overlap = total < c->overlap_below;
+    const size_t P = overlap ? c->pipes.size() : 1;
+    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / c->pipes.size() / per_sample, 4096);
     const uint32_t want = total >= (1u << 20) ? (uint32_t)P : 1u;
     std::vector<Batch> batches;
     if (pt.npix <= cap0 && spp >= want) {
@@ -375,7 +384,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         rc = reset_counters(c, pp);
         if (rc != RTX_OK) return rc;
         launch_raygen(c->ds, pp.fr, info, lc);
-        rc = run_levels(c, pp, lc, levels, timing, ev_per_batch * bi);
+        rc = run_levels(c, pp, lc, levels, timing, ev_per_batch * bi, overlap);
         if (rc != RTX_OK) return rc;
         // sums are folded in sample order (world.rs:54-61): accumulate follows the previous batch's
         if (bi > 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->chain[bi - 1], 0));
@@ -471,6 +480,8 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     c->stream = c->pipes[0].main;
     c->persistent_blocks = query_persistent_blocks(device);
+    if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: never, 1: always
+        c->overlap_below = std::atoi(ov) ? ~0ull : 0ull;
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
         long v = std::atol(mb);
         if (v > 0) c->node_budget_bytes = (uint64_t)v << 20;
@@ -749,7 +760,7 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         (void)reset_counters(c, pp);
         launch_load_rays(pp.fr, d_rays, m, lc);
         if (out_rgb) {
-            if (run_levels(c, pp, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
+            if (run_levels(c, pp, lc, levels, false, 0, false) != RTX_OK) e = hipErrorUnknown;
             launch_export_colors(pp.fr, m, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
         } else {
