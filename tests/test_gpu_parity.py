@@ -156,6 +156,25 @@ def test_sample_batching_is_exact(rt, gpu, monkeypatch):
         c2.close()
 
 
+def test_concurrent_and_serial_schedules_agree(rt, gpu, monkeypatch):
+    """Pipes + side stream (small renders) and the serial schedule must not differ in a byte."""
+    s = rt.HostScene("scan_glass", 512, 30000)
+    imgs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTX_CONCURRENT", mode)
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            img, st = c.render(spp=8, bounces=4, seed=5)
+            img1, st1 = c.render(spp=1, bounces=4)       # pixel-range batches
+            imgs.append((img, img1, st.rays, st1.rays, st.batches))
+        finally:
+            c.close()
+    assert np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][1], imgs[1][1])
+    assert imgs[0][2:4] == imgs[1][2:4]
+    assert imgs[1][4] >= 2 and imgs[0][4] == 1
+
+
 def test_errors(rt, gpu):
     c = rt.Context(0)
     with pytest.raises(rt.RtxError) as e:
