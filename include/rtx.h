@@ -91,7 +91,9 @@ typedef struct rtx_stats {
     uint64_t shadow_nodes, shadow_prims;    /* trace_shadow */
     double trace_ms;            /* host wall time raygen..resolve (stream-synchronised) */
     double closest_kernel_ms;   /* HIP-event time summed over trace_closest launches */
-    double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches */
+    double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches (launches that run
+                                   concurrently share the GPU: the sums can exceed the wall time) */
+    double trace_span_ms;       /* HIP-event time from the first trace launch's start to the last one's end */
     uint32_t closest_launches, shadow_launches;
     uint32_t batches;
     uint32_t max_ray_records;   /* most node + primitive records visited by one ray (COUNT_VISITS) */

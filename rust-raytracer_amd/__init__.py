@@ -48,6 +48,7 @@ class Stats(C.Structure):
                 ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64),
                 ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64),
                 ("trace_ms", C.c_double), ("closest_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
+                ("trace_span_ms", C.c_double),
                 ("closest_launches", C.c_uint32), ("shadow_launches", C.c_uint32),
                 ("batches", C.c_uint32), ("max_ray_records", C.c_uint32)]
 

@@ -32,8 +32,8 @@ struct Pipe {
     uint64_t node_cap = 0, q_cap = 0;
     uint32_t lights = 0, levels = 0;
     hipStream_t main = nullptr;
-    hipStream_t side = nullptr;       // trace_shadow(k) runs here, beside trace_closest(k+1)
-    uint32_t *spill_side = nullptr;   // traversal-stack overflow of the kernels on `side`
+    std::vector<hipStream_t> sides;   // trace_shadow(k) runs on sides[k % n], beside trace_closest(k+1)
+    std::vector<uint32_t *> spill_side;  // traversal-stack overflow of the kernels on each side stream
     std::vector<hipEvent_t> order;    // ordering events between the two streams (no timing)
 };
 
@@ -61,7 +61,7 @@ struct rtx_ctx {
     uint32_t h_counter_slots = 0;
     std::vector<hipEvent_t> events;
     uint64_t node_budget_bytes = 32ull << 30;
-    uint64_t overlap_below = 12ull << 20;  // renders with fewer primary samples use the pipes concurrently
+    uint64_t overlap_below = ~0ull;  // renders with fewer primary samples run their kernels concurrently (RTX_CONCURRENT=0: none)
 };
 
 namespace {
@@ -159,10 +159,10 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
         return RTX_OK;
     }
     HIP_TRY(c, hipStreamSynchronize(pp.main));
-    HIP_TRY(c, hipStreamSynchronize(pp.side));
+    for (auto sd : pp.sides) HIP_TRY(c, hipStreamSynchronize(sd));
     free_all(pp.allocs);
     pp.fr = Frame{};
-    pp.spill_side = nullptr;
+    pp.spill_side.assign(pp.sides.size(), nullptr);
     pp.node_cap = pp.q_cap = 0;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
@@ -178,7 +178,7 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
     size_t threads = (size_t)c->persistent_blocks * 256;
     HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
-    HIP_TRY(c, alloc((void **)&pp.spill_side, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
+    for (auto &sp : pp.spill_side) HIP_TRY(c, alloc((void **)&sp, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
     pp.node_cap = node_cap;
     pp.q_cap = q_cap;
     pp.lights = nl;
@@ -249,18 +249,20 @@ struct Batch {
 // long rays -- is filled by the other instead of idling the GPU eight times per frame.
 // Records 4 timing events per level starting at events[ev0] when timing is on.
 int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0, bool overlap) {
-    while (pp.order.size() < (size_t)levels + 1) {
+    const size_t ns = pp.sides.size();
+    if (ns == 0) overlap = false;
+    while (pp.order.size() < (size_t)levels + ns) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pp.order.push_back(e);
     }
     lc.stream = pp.main;
-    hipStream_t side = overlap ? pp.side : pp.main;
-    LaunchCfg ls = lc;
-    ls.stream = side;
-    Frame fs = pp.fr;
-    if (overlap) fs.spill = pp.spill_side;
     for (uint32_t k = 0; k < levels; k++) {
+        hipStream_t side = overlap ? pp.sides[k % ns] : pp.main;
+        LaunchCfg ls = lc;
+        ls.stream = side;
+        Frame fs = pp.fr;
+        if (overlap) fs.spill = pp.spill_side[k % ns];
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], pp.main);
         launch_trace_closest(c->ds, pp.fr, k, lc);
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], pp.main);
@@ -274,9 +276,12 @@ int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing,
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], side);
     }
     if (levels && overlap) {
-        HIP_TRY(c, hipEventRecord(pp.order[levels], side));
-        HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels], 0));
+        for (size_t j = 0; j < std::min<size_t>(ns, levels); j++) {
+            HIP_TRY(c, hipEventRecord(pp.order[levels + j], pp.sides[j]));
+            HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels + j], 0));
+        }
     }
+    if (timing) (void)hipEventRecord(c->events[ev0 + 4 * levels], pp.main);  // every trace launch has ended
     for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
     if (levels == 0) launch_resolve(c->ds, pp.fr, 0, lc);
     return RTX_OK;
@@ -310,10 +315,9 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     // range) that run concurrently, one per pipe, so that the serial tail of every persistent
     // kernel -- one ray can visit 500+ records against a mean of 9 -- overlaps another
     // piece's bulk instead of idling the GPU.  The node budget is shared between the pipes.
-    // A launch ends with its longest ray (~0.1-0.5 ms alone on the GPU), which is noise for a
-    // 16 M-sample frame but most of the time for a small share of one (multi-GPU tiles): small
-    // renders run concurrently (pipes + side stream), big ones serially -- which also keeps
-    // the per-kernel HIP-event times of the headline bench free of queueing behind another kernel.
+    // A launch ends with its longest ray (~0.1-0.5 ms alone on the GPU, eight launches per
+    // frame), so the kernels of one render run concurrently wherever the data allow it: the
+    // shadow kernels on side streams (run_levels) and, with RTX_PIPES > 1, batches on pipes.
     uint64_t total = pt.npix * spp;
     bool overlap = total < c->overlap_below;
     const size_t P = overlap ? c->pipes.size() : 1;
@@ -347,7 +351,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     rc = ensure_chain(c, batches.size());
     if (rc != RTX_OK) return rc;
     bool timing = stats != nullptr;
-    size_t ev_per_batch = 4 * (size_t)levels;
+    size_t ev_per_batch = 4 * (size_t)levels + 1;  // per level: closest begin/end, shadow begin/end; + joined
     if (timing) {
         rc = ensure_events(c, ev_per_batch * batches.size());
         if (rc != RTX_OK) return rc;
@@ -427,6 +431,11 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
             stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
             stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
+            if (levels) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, c->events[ev_per_batch * bi], c->events[ev_per_batch * bi + 4 * levels]) == hipSuccess)
+                    stats->trace_span_ms += ms;
+            }
             for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
                 size_t e = ev_per_batch * bi + 4 * k;
@@ -465,13 +474,18 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     rtx_ctx *c = new rtx_ctx();
     c->device = device;
-    int n_pipes = 2;
+    int n_pipes = 1;
     if (const char *np = std::getenv("RTX_PIPES")) n_pipes = std::min(4, std::max(1, std::atoi(np)));
+    int n_sides = 3;
+    if (const char *ns = std::getenv("RTX_SIDES")) n_sides = std::min(4, std::max(0, std::atoi(ns)));
     c->pipes.resize((size_t)n_pipes);
     e = hipEventCreateWithFlags(&c->start_ev, hipEventDisableTiming);
     for (auto &pp : c->pipes) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.main, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.side, hipStreamNonBlocking);
+        pp.sides.assign((size_t)n_sides, nullptr);
+        pp.spill_side.assign((size_t)n_sides, nullptr);
+        for (auto &sd : pp.sides)
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&sd, hipStreamNonBlocking);
     }
     if (e != hipSuccess) {
         g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -495,14 +509,16 @@ void rtx_destroy(rtx_ctx *c) {
     (void)hipSetDevice(c->device);
     for (auto &pp : c->pipes) {
         if (pp.main) (void)hipStreamSynchronize(pp.main);
-        if (pp.side) (void)hipStreamSynchronize(pp.side);
+        for (auto sd : pp.sides)
+            if (sd) (void)hipStreamSynchronize(sd);
     }
     free_all(c->scene_allocs);
     for (auto &pp : c->pipes) {
         free_all(pp.allocs);
         for (auto e : pp.order) (void)hipEventDestroy(e);
         if (pp.main) (void)hipStreamDestroy(pp.main);
-        if (pp.side) (void)hipStreamDestroy(pp.side);
+        for (auto sd : pp.sides)
+            if (sd) (void)hipStreamDestroy(sd);
     }
     if (c->sum) (void)hipFree(c->sum);
     if (c->tiles) (void)hipFree(c->tiles);
