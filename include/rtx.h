@@ -10,7 +10,8 @@
  * Conventions: every function returns RTX_OK (0) or a negative rtx_status and never
  * throws or aborts across the boundary; rtx_last_error() gives the text.  Input
  * pointers are borrowed for the duration of the call; output buffers are owned by the
- * caller.  One rtx_ctx per GPU, called from one host thread at a time.  The library
+ * caller.  One rtx_ctx per GPU, called from one host thread at a time (a render launches on
+ * several streams of its own and joins them into rtx_stream() before it returns).  The library
  * has no CPU fallback: without a usable HIP device rtx_init fails.
  */
 #ifndef RTX_H
@@ -86,7 +87,9 @@ typedef struct rtx_ctx rtx_ctx;
  * reference (world.rs:118, light.rs:90,111). */
 typedef struct rtx_stats {
     uint64_t primary_rays, bounce_rays, shadow_rays;
-    /* 64-byte records fetched, per kernel class; 0 unless RTX_FLAG_COUNT_VISITS is set */
+    /* records fetched, per kernel class; 0 unless RTX_FLAG_COUNT_VISITS is set.  Nodes are the
+     * 128-byte four-slot nodes (64-byte binary nodes under RTX_FLAG_REFERENCE_TRAVERSAL),
+     * primitives 64-byte records. */
     uint64_t closest_nodes, closest_prims;  /* trace_closest: internal nodes, primitive records */
     uint64_t shadow_nodes, shadow_prims;    /* trace_shadow */
     double trace_ms;            /* host wall time raygen..resolve (stream-synchronised) */
