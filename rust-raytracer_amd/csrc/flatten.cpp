@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <deque>
 
 namespace rtx {
 
@@ -58,18 +59,27 @@ struct EmitWide {
     }
     static uint32_t leaf_ref(const BuildNode &n) { return LEAF_BIT | (n.first << 3) | n.count; }
 
-    // Iterative (explicit work list): the tree can be deep.
+    // Iterative (explicit work list): the tree can be deep.  The first TOP_BFS nodes are
+    // numbered breadth-first (the kernels keep the top of the tree in LDS, indexed by node
+    // number), the rest depth-first for locality.
     void run(int32_t root) {
         struct Item {
             int32_t bn;
             uint32_t widx, level;
         };
-        std::vector<Item> work;
+        constexpr size_t TOP_BFS = 1024;
+        std::deque<Item> work;
         out.wnodes.emplace_back();
         work.push_back({root, 0, 1});
         while (!work.empty()) {
-            Item it = work.back();
-            work.pop_back();
+            Item it;
+            if (out.wnodes.size() < TOP_BFS) {  // nodes are numbered when their parent is processed
+                it = work.front();
+                work.pop_front();
+            } else {
+                it = work.back();
+                work.pop_back();
+            }
             if (it.level > out.wide_depth) out.wide_depth = it.level;
             const BuildNode &n = bvh.nodes[it.bn];
             int32_t slots[4] = {n.left, n.right, -1, -1};

@@ -307,7 +307,7 @@ static int add_mat_node(SceneArrays &s, const MaterialType &m) {
 
 int SceneArrays::add_material(const Material &m) {
     static const Material none = Material::make(MaterialType::None(), TextureType::None());
-    const MaterialData *d = m.d ? m.d.get() : none.d.get();
+    const std::shared_ptr<const MaterialData> &d = m.d ? m.d : none.d;
     for (size_t k = 0; k < mat_cache.size() && k < 64; k++) {
         const auto &e = mat_cache[mat_cache.size() - 1 - k];
         if (e.first == d) return e.second;
@@ -323,14 +323,14 @@ int SceneArrays::add_material(const Material &m) {
     if (t.kind == RTX_TEX_IMAGE) {
         tid = -1;
         for (auto &e : tex_cache)
-            if (e.first == t.image.get()) tid = e.second;
+            if (e.first == t.image) tid = e.second;
         if (tid < 0) {
             tid = (int)tex_w.size();
             tex_w.push_back((int)t.image->w);
             tex_h.push_back((int)t.image->h);
             tex_offset.push_back(tex_data.size());
             tex_data.insert(tex_data.end(), t.image->rgb.begin(), t.image->rgb.end());
-            tex_cache.push_back({t.image.get(), tid});
+            tex_cache.push_back({t.image, tid});
         }
     }
     mat_tex_id.push_back(tid);

@@ -120,8 +120,10 @@ struct SceneArrays {
     float background[3] = {0, 0, 0};
     M4 camera_to_world = m4_identity();
     uint32_t width = 0, height = 0;
-    std::vector<std::pair<const MaterialData *, int>> mat_cache;
-    std::vector<std::pair<const Image *, int>> tex_cache;
+    // interning by identity: the caches OWN a reference, so an address cannot be reused by
+    // a later allocation while its entry is alive
+    std::vector<std::pair<std::shared_ptr<const MaterialData>, int>> mat_cache;
+    std::vector<std::pair<std::shared_ptr<const Image>, int>> tex_cache;
 
     int add_xform(const M4 &o2w, const M4 &w2o);   // interned
     int add_material(const Material &m);           // interned by identity

@@ -19,7 +19,7 @@ struct DeviceScene {
     const uint8_t *tex_data;
     const LightRec *lights;
     const uint32_t *prim_obj;   // leaf-order primitive -> object index of the description
-    uint32_t n_prims, n_lights;
+    uint32_t n_prims, n_lights, n_wnodes;
     uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
     uint32_t wroot_ref;         // root in the wide tree (wide node 0 or the root leaf)
     uint32_t xf0_identity;      // transform 0 is exactly the identity

@@ -17,6 +17,16 @@ namespace rtx {
 namespace {
 
 constexpr int BLOCK = 256;
+// The first TOP_NODES wide nodes (numbered breadth-first by the flattener) are kept in LDS,
+// one dwordx4 piece per array ([piece][node]: lanes on different nodes read consecutive
+// 16-byte words, no bank conflicts): the top of the tree is where most node visits go, and
+// an LDS read costs neither an L1 tag lookup per lane nor an L2 round trip.
+#ifndef RTX_TOP_NODES
+#define RTX_TOP_NODES 128
+#endif
+constexpr uint32_t TOP_NODES = RTX_TOP_NODES;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f *LdsNodePtr;  // typed so the reads stay ds_read_b128
 constexpr uint32_t PRIM_IDENTITY_XFORM = 0x8000u;  // Prim::meta bit 15
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 4  // waves per SIMD the trace kernels are register-allocated for
@@ -389,13 +399,32 @@ __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack
 
 // Advances a lane that holds an internal node by one node.
 template <bool COUNT, bool REF>
-__device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st) {
+__device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st, LdsNodePtr lds_top) {
     uint32_t cur = s.cur;
     if (COUNT) s.nodes++;
     if constexpr (!REF) {
-        const float4 *np = reinterpret_cast<const float4 *>(sc.wnodes + cur);
-        float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
-        float4 rf4 = np[6];
+        float4 mnx, mny, mnz, mxx, mxy, mxz, rf4;
+        if (TOP_NODES != 0u && cur < TOP_NODES) {
+            LdsNodePtr lp = lds_top + cur;
+            v4f a = lp[0 * TOP_NODES], b = lp[1 * TOP_NODES], c = lp[2 * TOP_NODES], d = lp[3 * TOP_NODES];
+            v4f e = lp[4 * TOP_NODES], f = lp[5 * TOP_NODES], g = lp[6 * TOP_NODES];
+            mnx = make_float4(a.x, a.y, a.z, a.w);
+            mny = make_float4(b.x, b.y, b.z, b.w);
+            mnz = make_float4(c.x, c.y, c.z, c.w);
+            mxx = make_float4(d.x, d.y, d.z, d.w);
+            mxy = make_float4(e.x, e.y, e.z, e.w);
+            mxz = make_float4(f.x, f.y, f.z, f.w);
+            rf4 = make_float4(g.x, g.y, g.z, g.w);
+        } else {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.wnodes + cur);
+            mnx = np[0];
+            mny = np[1];
+            mnz = np[2];
+            mxx = np[3];
+            mxy = np[4];
+            mxz = np[5];
+            rf4 = np[6];
+        }
         uint32_t r0 = __float_as_uint(rf4.x), r1 = __float_as_uint(rf4.y), r2 = __float_as_uint(rf4.z),
                  r3 = __float_as_uint(rf4.w);
         float t0, t1, t2, t3, x0, x1, x2, x3;  // entry / exit t per slot
@@ -525,14 +554,14 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 #define RTX_LEAF_WEIGHT 1
 #endif
 template <int MODE, bool COUNT, bool REF>
-__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist) {
+__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist, LdsNodePtr lds_top) {
     bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
     bool at_node = !(s.cur & LEAF_BIT);
     uint32_t nl = (uint32_t)__popcll(__ballot(at_leaf)), nn = (uint32_t)__popcll(__ballot(at_node));
     if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn) {
         if (at_leaf) prim_step<MODE, COUNT, REF>(sc, s, st, dist);
     } else {
-        if (at_node) node_step<COUNT, REF>(sc, s, st);
+        if (at_node) node_step<COUNT, REF>(sc, s, st, lds_top);
     }
 }
 
@@ -674,6 +703,15 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
     __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
+    __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
+    const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
+    if (TOP_NODES != 0u && !REF) {
+        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += BLOCK) {
+            uint32_t piece = i / (TOP_NODES ? TOP_NODES : 1u), n = i % (TOP_NODES ? TOP_NODES : 1u);
+            lds_top_store[i] = n < sc.n_wnodes ? reinterpret_cast<const v4f *>(sc.wnodes + n)[piece] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
@@ -716,7 +754,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
         do {
             bool active = s.cur != TRAV_DONE;
             uint32_t before = s.nodes + s.prims;
-            wave_step<0, COUNT, REF>(sc, s, st, 0.0f);
+            wave_step<0, COUNT, REF>(sc, s, st, 0.0f, lds_top);
             if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 fr.ray_o[node].w = s.any ? s.t : 0.0f;
@@ -937,6 +975,15 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 template <bool COUNT, bool REF>
 __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
     __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
+    __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
+    const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
+    if (TOP_NODES != 0u && !REF) {
+        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += BLOCK) {
+            uint32_t piece = i / (TOP_NODES ? TOP_NODES : 1u), n = i % (TOP_NODES ? TOP_NODES : 1u);
+            lds_top_store[i] = n < sc.n_wnodes ? reinterpret_cast<const v4f *>(sc.wnodes + n)[piece] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
     const uint32_t nthreads = gridDim.x * BLOCK;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     Stack st;
@@ -996,7 +1043,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
             do {
                 bool active = s.cur != TRAV_DONE;
                 uint32_t before = s.nodes + s.prims;
-                wave_step<1, COUNT, REF>(sc, s, st, dist);
+                wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top);
                 if (COUNT) ray_steps += s.nodes + s.prims - before;
                 if (active && s.cur == TRAV_DONE) {
                     bool reaches = directional ? !s.any : (s.any && !s.occluded);

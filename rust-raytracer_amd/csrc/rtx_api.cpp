@@ -573,6 +573,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if ((rc = upload(c, fs.prim_obj, &ds.prim_obj, c->scene_allocs))) return rc;
     ds.n_prims = d->n_objects;
     ds.n_lights = (uint32_t)fs.lights.size();
+    ds.n_wnodes = (uint32_t)fs.wnodes.size();
     ds.root_ref = fs.root_ref;
     ds.wroot_ref = fs.wide_root_ref;
     ds.xf0_identity = fs.xf0_identity ? 1u : 0u;
