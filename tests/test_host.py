@@ -169,6 +169,10 @@ def test_builtin_scene_inventory(rt):
     assert (r.n_objects, r.n_lights) == (1005, 4)           # scene.rs:111-186
     c2 = rt.HostScene("basic_suzanne", 16).desc.contents
     assert (c2.n_objects, c2.n_lights) == (505, 6)
+    # every distinct Material is its own entry (interning must not match a freed material's address)
+    for _ in range(5):
+        assert rt.HostScene("basic_suzanne", 16).desc.contents.n_materials == 6
+        assert rt.HostScene("scan", 16, 2000).desc.contents.n_materials == 9
     sc = rt.HostScene("scan", 16, 0).desc.contents
     assert sc.n_objects == 2374525 + 5
     with pytest.raises(rt.RtxError):
