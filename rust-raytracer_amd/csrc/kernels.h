@@ -93,7 +93,11 @@ void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level
 void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level, uint32_t max_levels,
                           const LaunchCfg &lc);
 void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
-void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
+// Resolves the colours of a level's path nodes (material.rs:118-206).  RESOLVE_LEAVES: misses
+// and hits without bounce children (ready once the level's shadow answers exist);
+// RESOLVE_PARENTS: hits with bounce children (need the deeper levels); RESOLVE_ALL: both.
+enum ResolvePhase : uint32_t { RESOLVE_ALL = 0, RESOLVE_LEAVES = 1, RESOLVE_PARENTS = 2 };
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, ResolvePhase phase, const LaunchCfg &lc);
 // Adds the batch's sample colours to `sum` in sample order (world.rs:54-61); on the last
 // sample chunk divides by spp, clamps and quantises (world.rs:62-63, color.rs:25-31).
 void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum,

@@ -997,64 +997,74 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
     uint32_t node = 0;
     uint32_t ray_steps = 0, max_steps = 0;
     float dist = 0.0f;
+    // The lights' queues of this level form ONE index space (light 0's entries, then light
+    // 1's, ...): a wave drains -- runs its last, longest rays with most lanes idle -- once per
+    // launch instead of once per light.  The light of a lane's ray is per-lane state.
+    uint32_t light = 0;  // bits 7..0 light index, bit 8 directional
+    uint32_t total = 0;
     for (uint32_t l = 0; l < sc.n_lights; l++) {
-        const LightRec &L = sc.lights[l];
-        if (L.type == LIGHT_AMBIENT) continue;
-        uint32_t count = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
-        if (count > fr.q_cap) count = fr.q_cap;
-        const uint32_t *q = fr.shadow_q + ((size_t)level * sc.n_lights + l) * fr.q_cap;
-        const F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
-        const F3 ldir = f3(L.dir[0], L.dir[1], L.dir[2]);
-        const bool directional = L.type == 2u;
-        WaveQueue wq;
-        wq.init(fr.work + (size_t)(level * WORK_QUEUES + 1 + l) * (QPARTS * QHEAD_STRIDE), count, nthreads / 64u, gtid / 64u);
-        for (;;) {
-            unsigned long long idle = __ballot(s.cur == TRAV_DONE);
-            uint32_t nidle = (uint32_t)__popcll(idle);
-            if (wq.exhausted) {
-                if (nidle == 64u) break;
-            } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
-                uint32_t i;
-                if (wq.take(idle, s.cur == TRAV_DONE, i)) {
-                    node = q[i];
-                    float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
-                    if (directional) {
-                        // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
-                        F3 rd = normalize(-ldir);
-                        F3 ro = p + 1e-4f * rd;
-                        rd = normalize(rd);
-                        dist = INFINITY;  // any hit at all blocks a directional light
-                        init_ray(s.r, sc, ro, rd);
-                    } else {
-                        // Light::in_shadow (light.rs:81-97)
-                        F3 rd = normalize(p - lpos);
-                        dist = magnitude(lpos - p);
-                        init_ray(s.r, sc, lpos, rd);
-                    }
-                    trav_begin<REF>(sc, s, st);
-                    // a ray that misses the root box hits nothing: directional light reaches,
-                    // point / cone light does not (light.rs:93-96)
-                    if (s.cur == TRAV_DONE && directional) atomicOr(&fr.link[node].x, 1u << l);
+        uint32_t c = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
+        total += c > fr.q_cap ? fr.q_cap : c;
+    }
+    WaveQueue wq;
+    wq.init(fr.work + (size_t)(level * WORK_QUEUES + 1) * (QPARTS * QHEAD_STRIDE), total, nthreads / 64u, gtid / 64u);
+    for (;;) {
+        unsigned long long idle = __ballot(s.cur == TRAV_DONE);
+        uint32_t nidle = (uint32_t)__popcll(idle);
+        if (wq.exhausted) {
+            if (nidle == 64u) break;
+        } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
+            uint32_t i;
+            if (wq.take(idle, s.cur == TRAV_DONE, i)) {
+                uint32_t l = 0;
+                for (; l + 1u < sc.n_lights; l++) {  // ambient lights have empty queues
+                    uint32_t c = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
+                    c = c > fr.q_cap ? fr.q_cap : c;
+                    if (i < c) break;
+                    i -= c;
                 }
-                continue;
+                const LightRec &L = sc.lights[l];
+                const bool directional = L.type == LIGHT_DIRECTIONAL;
+                light = l | (directional ? 0x100u : 0u);
+                node = fr.shadow_q[((size_t)level * sc.n_lights + l) * fr.q_cap + i];
+                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
+                if (directional) {
+                    // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
+                    F3 rd = normalize(-f3(L.dir[0], L.dir[1], L.dir[2]));
+                    F3 ro = p + 1e-4f * rd;
+                    rd = normalize(rd);
+                    dist = INFINITY;  // any hit at all blocks a directional light
+                    init_ray(s.r, sc, ro, rd);
+                } else {
+                    // Light::in_shadow (light.rs:81-97)
+                    const F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
+                    F3 rd = normalize(p - lpos);
+                    dist = magnitude(lpos - p);
+                    init_ray(s.r, sc, lpos, rd);
+                }
+                trav_begin<REF>(sc, s, st);
+                // a ray that misses the root box hits nothing: directional light reaches,
+                // point / cone light does not (light.rs:93-96)
+                if (s.cur == TRAV_DONE && directional) atomicOr(&fr.link[node].x, 1u << l);
             }
-            const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
-            do {
-                bool active = s.cur != TRAV_DONE;
-                uint32_t before = s.nodes + s.prims;
-                wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top);
-                if (COUNT) ray_steps += s.nodes + s.prims - before;
-                if (active && s.cur == TRAV_DONE) {
-                    bool reaches = directional ? !s.any : (s.any && !s.occluded);
-                    if (reaches) atomicOr(&fr.link[node].x, 1u << l);
-                    if (COUNT) {
-                        max_steps = ray_steps > max_steps ? ray_steps : max_steps;
-                        ray_steps = 0;
-                    }
-                }
-            } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
+            continue;
         }
+        const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
+        do {
+            bool active = s.cur != TRAV_DONE;
+            uint32_t before = s.nodes + s.prims;
+            wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top);
+            if (COUNT) ray_steps += s.nodes + s.prims - before;
+            if (active && s.cur == TRAV_DONE) {
+                bool reaches = (light & 0x100u) ? !s.any : (s.any && !s.occluded);
+                if (reaches) atomicOr(&fr.link[node].x, 1u << (light & 0xFFu));
+                if (COUNT) {
+                    max_steps = ray_steps > max_steps ? ray_steps : max_steps;
+                    ray_steps = 0;
+                }
+            }
+        } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
     }
     if (COUNT) {
         add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
@@ -1102,7 +1112,7 @@ __device__ __forceinline__ F3 texture_sample(const DeviceScene &sc, const Materi
     return crgb(0.5f, 0.5f, 0.5f);
 }
 
-__global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+__global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level, uint32_t phase) {
     const uint32_t base = level_base(fr.counters, level);
     const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
     const uint32_t nthreads = gridDim.x * BLOCK;
@@ -1112,10 +1122,12 @@ __global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr
         float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
         uint32_t prim = __float_as_uint(d4.w);
         F3 res;
-        if (prim == INVALID_PRIM) res = f3(0.f, 0.f, 0.f);
-        else if (prim == NO_PRIM) res = bg;  // world.rs:127-130
-        else {
+        if (prim >= INVALID_PRIM) {
+            if (phase == RESOLVE_PARENTS) continue;
+            res = prim == INVALID_PRIM ? f3(0.f, 0.f, 0.f) : bg;  // world.rs:127-130
+        } else {
             uint2 lk = fr.link[node];
+            if (phase != RESOLVE_ALL && (phase == RESOLVE_PARENTS) != (lk.y != NO_PRIM)) continue;
             F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
             F3 p = o + o4.w * d;
             PrimView pv = load_prim(sc.prims + prim);
@@ -1273,8 +1285,8 @@ void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level
     hipLaunchKernelGGL(shade_forward_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level,
                        max_levels);
 }
-void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
-    hipLaunchKernelGGL(resolve_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level);
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, ResolvePhase phase, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(resolve_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level, (uint32_t)phase);
 }
 void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum, uint8_t *tiles_rgb8,
                        float *tiles_f32, const LaunchCfg &lc) {

@@ -274,6 +274,9 @@ int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing,
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], side);
         launch_trace_shadow(c->ds, fs, k, ls);
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], side);
+        // hits without bounce children depend on nothing deeper: their colours are resolved
+        // as soon as the level's shadow answers exist, beside the deeper levels' traversal
+        if (overlap) launch_resolve(c->ds, pp.fr, k, RESOLVE_LEAVES, ls);
     }
     if (levels && overlap) {
         for (size_t j = 0; j < std::min<size_t>(ns, levels); j++) {
@@ -281,9 +284,10 @@ int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing,
             HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels + j], 0));
         }
     }
-    if (timing) (void)hipEventRecord(c->events[ev0 + 4 * levels], pp.main);  // every trace launch has ended
-    for (int k = (int)levels - 1; k >= 0; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
-    if (levels == 0) launch_resolve(c->ds, pp.fr, 0, lc);
+    // the deepest level spawns no children, so with `overlap` it is already complete
+    for (int k = (int)levels - (overlap ? 2 : 1); k >= 0; k--)
+        launch_resolve(c->ds, pp.fr, (uint32_t)k, overlap ? RESOLVE_PARENTS : RESOLVE_ALL, lc);
+    if (levels == 0) launch_resolve(c->ds, pp.fr, 0, RESOLVE_ALL, lc);
     return RTX_OK;
 }
 
@@ -351,7 +355,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     rc = ensure_chain(c, batches.size());
     if (rc != RTX_OK) return rc;
     bool timing = stats != nullptr;
-    size_t ev_per_batch = 4 * (size_t)levels + 1;  // per level: closest begin/end, shadow begin/end; + joined
+    size_t ev_per_batch = 4 * (size_t)levels;  // per level: closest begin/end, shadow begin/end
     if (timing) {
         rc = ensure_events(c, ev_per_batch * batches.size());
         if (rc != RTX_OK) return rc;
@@ -431,11 +435,13 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
             stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
             stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
-            if (levels) {
+            float span = 0;  // first trace launch begins .. last one ends (they overlap)
+            for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
-                if (hipEventElapsedTime(&ms, c->events[ev_per_batch * bi], c->events[ev_per_batch * bi + 4 * levels]) == hipSuccess)
-                    stats->trace_span_ms += ms;
+                for (size_t e : {ev_per_batch * bi + 4 * k + 1, ev_per_batch * bi + 4 * k + 3})
+                    if (hipEventElapsedTime(&ms, c->events[ev_per_batch * bi], c->events[e]) == hipSuccess) span = std::max(span, ms);
             }
+            stats->trace_span_ms += span;
             for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
                 size_t e = ev_per_batch * bi + 4 * k;
