@@ -44,7 +44,8 @@ enum {
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
     CTR_MAX_STEPS,                          // most records visited by a single ray (COUNT)
-    CTR_WORDS = 160
+    CTR_UTIL = 148,                         // [2][5] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
+    CTR_WORDS = 168
 };
 // Queue heads of the persistent trace kernels live in their own buffer (Frame::work): per
 // bounce level WORK_QUEUES queues (0 = trace_closest, 1 + l = trace_shadow of light l), each

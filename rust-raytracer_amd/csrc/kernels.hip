@@ -553,14 +553,44 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 #ifndef RTX_LEAF_WEIGHT
 #define RTX_LEAF_WEIGHT 1
 #endif
+// Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
+// tools/util_probe.py prints it): wave steps and executing lanes per kind.
+struct Util {
+    uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
+    __device__ __forceinline__ void flush(uint32_t *ctr) {
+#ifdef RTX_UTIL_STATS
+        if (lane_id() == 0) {
+            unsigned long long *c = reinterpret_cast<unsigned long long *>(ctr + CTR_UTIL);
+            atomicAdd(c + 0, (unsigned long long)node_steps);
+            atomicAdd(c + 1, (unsigned long long)prim_steps);
+            atomicAdd(c + 2, (unsigned long long)node_lanes);
+            atomicAdd(c + 3, (unsigned long long)prim_lanes);
+            atomicAdd(c + 4, (unsigned long long)done_lanes);
+        }
+#endif
+    }
+};
+
 template <int MODE, bool COUNT, bool REF>
-__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist, LdsNodePtr lds_top) {
+__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist, LdsNodePtr lds_top,
+                                          Util &u) {
     bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
     bool at_node = !(s.cur & LEAF_BIT);
     uint32_t nl = (uint32_t)__popcll(__ballot(at_leaf)), nn = (uint32_t)__popcll(__ballot(at_node));
+#ifdef RTX_UTIL_STATS
+    u.done_lanes += 64u - nl - nn;
+#endif
     if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn) {
+#ifdef RTX_UTIL_STATS
+        u.prim_steps++;
+        u.prim_lanes += nl;
+#endif
         if (at_leaf) prim_step<MODE, COUNT, REF>(sc, s, st, dist);
     } else {
+#ifdef RTX_UTIL_STATS
+        u.node_steps++;
+        u.node_lanes += nn;
+#endif
         if (at_node) node_step<COUNT, REF>(sc, s, st, lds_top);
     }
 }
@@ -725,6 +755,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
     s.nodes = s.prims = 0;
     uint32_t node = 0;
     uint32_t ray_steps = 0, max_steps = 0;  // COUNT: records visited by the current ray / the longest ray
+    Util util;
     WaveQueue wq;
     wq.init(fr.work + (size_t)(level * WORK_QUEUES) * (QPARTS * QHEAD_STRIDE), fr.counters[CTR_LEVEL_COUNT + level],
             nthreads / 64u, gtid / 64u);
@@ -754,7 +785,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
         do {
             bool active = s.cur != TRAV_DONE;
             uint32_t before = s.nodes + s.prims;
-            wave_step<0, COUNT, REF>(sc, s, st, 0.0f, lds_top);
+            wave_step<0, COUNT, REF>(sc, s, st, 0.0f, lds_top, util);
             if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 fr.ray_o[node].w = s.any ? s.t : 0.0f;
@@ -766,6 +797,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(D
             }
         } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
     }
+    util.flush(fr.counters);
     if (COUNT) {
         add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
         atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
@@ -996,6 +1028,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
     s.nodes = s.prims = 0;
     uint32_t node = 0;
     uint32_t ray_steps = 0, max_steps = 0;
+    Util util;
     float dist = 0.0f;
     // The lights' queues of this level form ONE index space (light 0's entries, then light
     // 1's, ...): a wave drains -- runs its last, longest rays with most lanes idle -- once per
@@ -1054,7 +1087,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
         do {
             bool active = s.cur != TRAV_DONE;
             uint32_t before = s.nodes + s.prims;
-            wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top);
+            wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top, util);
             if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 bool reaches = (light & 0x100u) ? !s.any : (s.any && !s.occluded);
@@ -1066,6 +1099,7 @@ __global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(De
             }
         } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
     }
+    util.flush(fr.counters + 10);
     if (COUNT) {
         add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
         atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);

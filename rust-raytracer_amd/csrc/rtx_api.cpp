@@ -258,11 +258,14 @@ int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing,
     }
     lc.stream = pp.main;
     for (uint32_t k = 0; k < levels; k++) {
-        hipStream_t side = overlap ? pp.sides[k % ns] : pp.main;
+        // level 0's shadow launch is by far the longest: it has side stream 0 to itself, so
+        // that a deep level's short one does not queue behind it
+        const size_t sk = (k == 0 || ns == 1) ? 0 : 1 + (k - 1) % (ns - 1);
+        hipStream_t side = overlap ? pp.sides[sk] : pp.main;
         LaunchCfg ls = lc;
         ls.stream = side;
         Frame fs = pp.fr;
-        if (overlap) fs.spill = pp.spill_side[k % ns];
+        if (overlap) fs.spill = pp.spill_side[sk];
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], pp.main);
         launch_trace_closest(c->ds, pp.fr, k, lc);
         if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], pp.main);
@@ -435,6 +438,13 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
             stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
             stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
+            if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
+                const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
+                for (int k = 0; k < 2; k++)
+                    std::fprintf(stderr, "util %s node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu\n",
+                                 k ? "shadow" : "closest", (unsigned long long)u[5 * k], (unsigned long long)u[5 * k + 1],
+                                 (unsigned long long)u[5 * k + 2], (unsigned long long)u[5 * k + 3], (unsigned long long)u[5 * k + 4]);
+            }
             float span = 0;  // first trace launch begins .. last one ends (they overlap)
             for (uint32_t k = 0; k < levels; k++) {
                 float ms = 0;
