@@ -12,17 +12,25 @@
 //   accumulate      world.rs:61-63 + color.rs:25-31
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace rtx {
 
 namespace {
 
 constexpr int BLOCK = 256;
+// Threads per block of the two persistent trace kernels (measured: 64 / 128 / 256 equal on
+// the headline frame, 512 / 1024 -10..15 %: wave slots come back block by block).
+#ifndef RTX_TRACE_BLOCK
+#define RTX_TRACE_BLOCK 256
+#endif
+constexpr int TBLOCK = RTX_TRACE_BLOCK;
 // The first TOP_NODES wide nodes (numbered breadth-first by the flattener) are kept in LDS,
 // one dwordx4 piece per array ([piece][node]: lanes on different nodes read consecutive
 // 16-byte words, no bank conflicts): the top of the tree is where most node visits go, and
 // an LDS read costs neither an L1 tag lookup per lane nor an L2 round trip.
 #ifndef RTX_TOP_NODES
-#define RTX_TOP_NODES 128
+#define RTX_TOP_NODES (RTX_TRACE_BLOCK / 4)
 #endif
 constexpr uint32_t TOP_NODES = RTX_TOP_NODES;
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -323,7 +331,7 @@ struct Stack {
     int sp;
     __device__ __forceinline__ void push(uint32_t ref, float t) {
         unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(t) << 32);
-        if (sp < LDS_STACK) lds[sp * BLOCK] = e;
+        if (sp < LDS_STACK) lds[sp * TBLOCK] = e;
         else spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
         sp++;
     }
@@ -332,7 +340,7 @@ struct Stack {
         while (sp > 0) {
             sp--;
             unsigned long long e;
-            if (sp < LDS_STACK) e = lds[sp * BLOCK];
+            if (sp < LDS_STACK) e = lds[sp * TBLOCK];
             else e = spill[(size_t)(sp - LDS_STACK) * spill_stride];
             if (!(__uint_as_float((uint32_t)(e >> 32)) > limit_plus)) return (uint32_t)e;
         }
@@ -731,20 +739,20 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 
 // ---------------------------------------------------------------- trace_closest
 template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
     if (TOP_NODES != 0u && !REF) {
-        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += BLOCK) {
+        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += TBLOCK) {
             uint32_t piece = i / (TOP_NODES ? TOP_NODES : 1u), n = i % (TOP_NODES ? TOP_NODES : 1u);
             lds_top_store[i] = n < sc.n_wnodes ? reinterpret_cast<const v4f *>(sc.wnodes + n)[piece] : v4f{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
     }
     const uint32_t base = level_base(fr.counters, level);
-    const uint32_t nthreads = gridDim.x * BLOCK;
-    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * TBLOCK;
+    const uint32_t gtid = blockIdx.x * TBLOCK + threadIdx.x;
     Stack st;
     st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
     st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
@@ -1005,19 +1013,19 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 
 // ---------------------------------------------------------------- trace_shadow
 template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(BLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    __shared__ unsigned long long lds_stack[LDS_STACK * BLOCK];
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
     if (TOP_NODES != 0u && !REF) {
-        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += BLOCK) {
+        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += TBLOCK) {
             uint32_t piece = i / (TOP_NODES ? TOP_NODES : 1u), n = i % (TOP_NODES ? TOP_NODES : 1u);
             lds_top_store[i] = n < sc.n_wnodes ? reinterpret_cast<const v4f *>(sc.wnodes + n)[piece] : v4f{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
     }
-    const uint32_t nthreads = gridDim.x * BLOCK;
-    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * TBLOCK;
+    const uint32_t gtid = blockIdx.x * TBLOCK + threadIdx.x;
     Stack st;
     st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
     st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
@@ -1295,7 +1303,7 @@ void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const L
     hipLaunchKernelGGL(load_rays_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, org_dir, n);
 }
 void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
-    dim3 g(lc.persistent_blocks), b(BLOCK);
+    dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
     if (lc.reference_traversal) {
         if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_closest_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
@@ -1305,7 +1313,7 @@ void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level
     }
 }
 void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
-    dim3 g(lc.persistent_blocks), b(BLOCK);
+    dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
     if (lc.reference_traversal) {
         if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_shadow_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
@@ -1340,11 +1348,11 @@ int query_persistent_blocks(int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_closest_kernel<false, false>, BLOCK, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_closest_kernel<false, false>, TBLOCK, 0) !=
             hipSuccess ||
         per_cu < 1)
-        per_cu = 4;
-    return prop.multiProcessorCount * per_cu;
+        per_cu = 4 * BLOCK / TBLOCK;
+    return prop.multiProcessorCount * per_cu * TBLOCK / BLOCK;  // in units of BLOCK threads
 }
 
 }  // namespace rtx
