@@ -445,38 +445,36 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         // reference's divisions; rare, so it sits behind ONE wave-uniform branch and reloads
         // the slot's box instead of keeping it live
         const bool eo = s.r.exact_only;
-        uint32_t need = 0, hits = 0;
-        {
-            // branch-free: (int32)ref < -1  <=>  leaf slot that is not WIDE_EMPTY
-            bool v0 = r0 != WIDE_EMPTY, v1 = r1 != WIDE_EMPTY, v2 = r2 != WIDE_EMPTY, v3 = r3 != WIDE_EMPTY;
-            bool n0 = (eo & v0) | (((int32_t)r0 < -1) & !m0 & !s0);
-            bool n1 = (eo & v1) | (((int32_t)r1 < -1) & !m1 & !s1);
-            bool n2 = (eo & v2) | (((int32_t)r2 < -1) & !m2 & !s2);
-            bool n3 = (eo & v3) | (((int32_t)r3 < -1) & !m3 & !s3);
-            need = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
-            hits = ((v0 & !m0) ? 1u : 0u) | ((v1 & !m1) ? 2u : 0u) | ((v2 & !m2) ? 4u : 0u) | ((v3 & !m3) ? 8u : 0u);
-        }
-        if (__ballot(need != 0u) != 0ull) {
+        // branch-free: (int32)ref < -1  <=>  leaf slot that is not WIDE_EMPTY
+        bool k0 = (r0 != WIDE_EMPTY) & !m0, k1 = (r1 != WIDE_EMPTY) & !m1;  // box passed (so far)
+        bool k2 = (r2 != WIDE_EMPTY) & !m2, k3 = (r3 != WIDE_EMPTY) & !m3;
+        const bool marginal = (((int32_t)r0 < -1) & !m0 & !s0) | (((int32_t)r1 < -1) & !m1 & !s1) |
+                              (((int32_t)r2 < -1) & !m2 & !s2) | (((int32_t)r3 < -1) & !m3 & !s3);
+        if (__ballot(eo | marginal) != 0ull) {
 #pragma unroll 1
             for (uint32_t k = 0; k < 4u; k++) {
-                if (need & (1u << k)) {
-                    const float *nb = reinterpret_cast<const float *>(sc.wnodes + cur) + k;
+                const float *nb = reinterpret_cast<const float *>(sc.wnodes + cur) + k;
+                const uint32_t rk = reinterpret_cast<const uint32_t *>(sc.wnodes + cur)[24 + k];
+                const float bx0 = nb[0], by0 = nb[4], bz0 = nb[8], bx1 = nb[12], by1 = nb[16], bz1 = nb[20];
+                float tk, xk;
+                bool mk, sk;
+                slab_fast(bx0, by0, bz0, bx1, by1, bz1, s.r, tk, xk, mk, sk);
+                if ((eo & (rk != WIDE_EMPTY)) | (((int32_t)rk < -1) & !mk & !sk)) {
                     float a, b;
-                    bool h = box_exact(nb[0], nb[4], nb[8], nb[12], nb[16], nb[20], s.r.o, s.r.d, a, b);
-                    hits = h ? (hits | (1u << k)) : (hits & ~(1u << k));
-                    if (k == 0u) { t0 = a; x0 = b; }
-                    if (k == 1u) { t1 = a; x1 = b; }
-                    if (k == 2u) { t2 = a; x2 = b; }
-                    if (k == 3u) { t3 = a; x3 = b; }
+                    bool h = box_exact(bx0, by0, bz0, bx1, by1, bz1, s.r.o, s.r.d, a, b);
+                    if (k == 0u) { k0 = h; t0 = a; x0 = b; }
+                    if (k == 1u) { k1 = h; t1 = a; x1 = b; }
+                    if (k == 2u) { k2 = h; t2 = a; x2 = b; }
+                    if (k == 3u) { k3 = h; t3 = a; x3 = b; }
                 }
             }
         }
         // pruning: box behind the origin or beyond the best hit
         const float back = -s.r.slack0, lim = s.limit_plus;
-        bool h0 = (hits & 1u) && !(x0 < back) && !(t0 > lim);
-        bool h1 = (hits & 2u) && !(x1 < back) && !(t1 > lim);
-        bool h2 = (hits & 4u) && !(x2 < back) && !(t2 > lim);
-        bool h3 = (hits & 8u) && !(x3 < back) && !(t3 > lim);
+        bool h0 = k0 && !(x0 < back) && !(t0 > lim);
+        bool h1 = k1 && !(x1 < back) && !(t1 > lim);
+        bool h2 = k2 && !(x2 < back) && !(t2 > lim);
+        bool h3 = k3 && !(x3 < back) && !(t3 > lim);
         t0 = h0 ? fminf(t0, 3.0e38f) : INFINITY;
         t1 = h1 ? fminf(t1, 3.0e38f) : INFINITY;
         t2 = h2 ? fminf(t2, 3.0e38f) : INFINITY;
