@@ -100,7 +100,7 @@ constexpr int MAX_LIGHTS = 16;
 constexpr int MAX_BOUNCE_LEAVES = 4;   // bounce leaves per material
 constexpr int MAX_COMP_DEPTH = 4;      // nesting of Composition
 #ifndef RTX_LDS_STACK
-#define RTX_LDS_STACK 16
+#define RTX_LDS_STACK 14
 #endif
 constexpr int LDS_STACK = RTX_LDS_STACK;          // per-lane traversal stack entries kept in LDS
 constexpr int MAX_TREE_DEPTH = 200;    // LDS_STACK + global spill entries per lane

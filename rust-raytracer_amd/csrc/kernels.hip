@@ -30,14 +30,14 @@ constexpr int TBLOCK = RTX_TRACE_BLOCK;
 // 16-byte words, no bank conflicts): the top of the tree is where most node visits go, and
 // an LDS read costs neither an L1 tag lookup per lane nor an L2 round trip.
 #ifndef RTX_TOP_NODES
-#define RTX_TOP_NODES (RTX_TRACE_BLOCK / 4)
+#define RTX_TOP_NODES (RTX_TRACE_BLOCK / 16)
 #endif
 constexpr uint32_t TOP_NODES = RTX_TOP_NODES;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f *LdsNodePtr;  // typed so the reads stay ds_read_b128
 constexpr uint32_t PRIM_IDENTITY_XFORM = 0x8000u;  // Prim::meta bit 15
 #ifndef RTX_TRACE_WAVES
-#define RTX_TRACE_WAVES 4  // waves per SIMD the trace kernels are register-allocated for
+#define RTX_TRACE_WAVES 5  // waves per SIMD the trace kernels are register-allocated for (<= 96 VGPRs)
 #endif
 
 // ---------------------------------------------------------------- cgmath-order arithmetic
