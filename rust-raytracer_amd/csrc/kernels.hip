@@ -129,6 +129,8 @@ __device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t lev
 struct RayCtx {
     F3 o, d;        // world ray (d normalised by Ray::new)
     F3 inv;         // 1/d, correctly rounded
+    F3 oi;          // o * inv (rounded): the slab planes are fma(plane, inv, -oi)
+    float delta0;   // absolute part of the slab error band (from the rounding of oi)
     F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
     uint32_t xf;
     bool exact_only;  // a zero / non-finite component: always take the division path
@@ -158,6 +160,8 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.slack0 = 1.5e-5f * (sc.coord_scale + m);
+    r.oi = f3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    r.delta0 = 2.4e-7f * fmaxf(fmaxf(fabsf(r.oi.x), fabsf(r.oi.y)), fabsf(r.oi.z));
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 
@@ -362,14 +366,19 @@ __device__ __forceinline__ void cswap(float &ta, uint32_t &ra, float &tb, uint32
 // Reciprocal slab test of one box (not for exact_only rays): entry/exit t, `miss` when the
 // intervals are clearly separated, `sure` when they clearly overlap; anything else is
 // within the f32 error of the reference's division form and must be decided by box_exact.
+// One fused multiply-add per plane, p*inv - o*inv.  Against the reference's fl(fl(p - o) / d),
+// with u = 2^-24: inv and o*inv carry one rounding each, the fma one, the reference two, so a
+// plane differs by at most 4u|t| + u|o*inv| (+ O(u^2)); max/min of planes inherit the bound,
+// and two interval ends are decided only when they are further apart than
+// 2*(5u*max|t| + 2u*max|o*inv|) <= 7.2e-7*max|t| + delta0.
 __device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                           const RayCtx &r, float &tmin, float &tmax, bool &miss, bool &sure) {
-    float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
-    float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
-    float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
+    float ax = __builtin_fmaf(mnx, r.inv.x, -r.oi.x), bx = __builtin_fmaf(mxx, r.inv.x, -r.oi.x);
+    float ay = __builtin_fmaf(mny, r.inv.y, -r.oi.y), by = __builtin_fmaf(mxy, r.inv.y, -r.oi.y);
+    float az = __builtin_fmaf(mnz, r.inv.z, -r.oi.z), bz = __builtin_fmaf(mxz, r.inv.z, -r.oi.z);
     tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
+    float delta = __builtin_fmaf(fmaxf(fabsf(tmin), fabsf(tmax)), 7.2e-7f, r.delta0);
     miss = tmin > tmax + delta;
     sure = tmin <= tmax - delta;
 }
