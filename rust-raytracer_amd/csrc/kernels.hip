@@ -159,9 +159,12 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
                isfinite(o.z);
     r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    r.slack0 = 1.5e-5f * (sc.coord_scale + m);
     r.oi = f3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
     r.delta0 = 2.4e-7f * fmaxf(fmaxf(fabsf(r.oi.x), fabsf(r.oi.y)), fabsf(r.oi.z));
+    // pruning compares slab t values (error <= 4u|t| + u|o*inv|, see slab_fast) with hit t
+    // values: the slack carries the absolute part of that error too -- for a ray nearly
+    // parallel to an axis |o*inv| is large and 1.5e-5*scale alone would be too tight
+    r.slack0 = 1.5e-5f * (sc.coord_scale + m) + r.delta0;
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 

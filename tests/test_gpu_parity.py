@@ -106,6 +106,57 @@ def test_secondary_rays_bit_exact(rt, orc, gpu):
     assert np.array_equal(obj_r, obj_o)
 
 
+def _world_vertices(s):
+    """World-space vertices of the scene's triangles and quads (float64 product of the f32 data)."""
+    d = s.desc.contents
+    n = d.n_objects
+    typ = np.ctypeslib.as_array(d.obj_type, (n,))
+    verts = np.ctypeslib.as_array(d.obj_verts, (n, 12)).astype(np.float64)
+    xf = np.ctypeslib.as_array(d.obj_xform, (n,))
+    mats = np.ctypeslib.as_array(d.xforms, (d.n_xforms, 32)).astype(np.float64)
+    out = []
+    for i in np.nonzero(typ != 0)[0]:
+        m = mats[xf[i], :16].reshape(4, 4).T  # column-major object_to_world
+        nv = 4 if typ[i] == 2 else 3
+        for k in range(nv):
+            v = m @ np.append(verts[i, 3 * k:3 * k + 3], 1.0)
+            out.append(v[:3] / v[3])
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name,width,param", [("basic_suzanne", 32, 0), ("scan", 32, 20000)])
+def test_grazing_rays_bit_exact(rt, orc, gpu, name, width, param):
+    """Rays aimed at mesh vertices and along triangle edges, from near and from far away: they
+    pass through corners and faces of leaf boxes (the slab test's error band, box_exact) and
+    through edges shared by triangles (sign-of-zero edge tests, ties in t)."""
+    s, o = _pair(rt, orc, gpu, name, width, param)
+    vw = _world_vertices(s)
+    rng = np.random.default_rng(11)
+    n = 24000
+    tgt = vw[rng.integers(0, len(vw), n)]
+    org = rng.uniform(-6, 6, (n, 3))
+    org[n // 3:2 * n // 3] *= 300.0          # far origins: large o * (1/d) in the slab planes
+    k = 2 * n // 3                            # rays along an edge: through two vertices of one primitive
+    a = vw[(rng.integers(0, len(vw) // 3, n - k)) * 3]
+    b = vw[(rng.integers(0, len(vw) // 3, n - k)) * 3 + 1]
+    org[k:] = a - (b - a) * rng.uniform(0.5, 40.0, (n - k, 1))
+    tgt[k:] = b
+    # nearly axis-parallel rays through vertices: one direction component ~1e-4 of the others,
+    # so o * (1/d) is in the thousands and the slab t values carry a large absolute error
+    m = n // 6
+    ax = rng.integers(0, 3, m)
+    off = rng.uniform(-5, 5, (m, 3))
+    off[np.arange(m), ax] = rng.uniform(-1e-3, 1e-3, m)
+    org[:m] = tgt[:m] - off
+    rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    obj_o, t_o = o.trace_rays(rays)
+    for flags in (0, rt.FLAG_REFERENCE_TRAVERSAL):
+        obj_g, t_g = gpu.trace_rays(rays, flags=flags)
+        assert np.array_equal(obj_g, obj_o)
+        assert np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    assert (obj_o != 0xFFFFFFFF).mean() > 0.3
+
+
 def test_reference_bvh_known_answers_on_device(rt, gpu):
     """bvh.rs:494-540 (test_bvh_intersect) on the device."""
     from test_oracle_kat import BVH_OBJECTS, BVH_RAYS
