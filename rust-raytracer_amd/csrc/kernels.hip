@@ -36,6 +36,17 @@ constexpr uint32_t TOP_NODES = RTX_TOP_NODES;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) v4f *LdsNodePtr;  // typed so the reads stay ds_read_b128
 constexpr uint32_t PRIM_IDENTITY_XFORM = 0x8000u;  // Prim::meta bit 15
+// |1/d_i| beyond which axis i is left out of pruning, and the pruning slack per unit of scene
+// scale (init_ray): a hit point and the faces of its leaf box agree to delta ~ 2.2e-7 * (scale
+// + |o|) in space (f32 matrix products on coordinates of that size), i.e. delta * ILL_INV in t
+// over the axes pruning looks at; SLACK covers that (1.4e-5) with the f32 error of t itself.
+#ifndef RTX_ILL_INV
+#define RTX_ILL_INV 64.0f
+#endif
+#ifndef RTX_SLACK
+#define RTX_SLACK 2.4e-5f
+#endif
+constexpr float ILL_INV = RTX_ILL_INV;  // |1/d_i| beyond which axis i is left out of pruning (init_ray)
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 5  // waves per SIMD the trace kernels are register-allocated for (<= 96 VGPRs)
 #endif
@@ -129,11 +140,10 @@ __device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t lev
 struct RayCtx {
     F3 o, d;        // world ray (d normalised by Ray::new)
     F3 inv;         // 1/d, correctly rounded
-    F3 oi;          // o * inv (rounded): the slab planes are fma(plane, inv, -oi)
-    float delta0;   // absolute part of the slab error band (from the rounding of oi)
     F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
     uint32_t xf;
     bool exact_only;  // a zero / non-finite component: always take the division path
+    uint32_t ill;     // bit i: axis i is ill-conditioned for pruning (|1/d_i| > ILL_INV), see init_ray
     float slack0;     // absolute pruning slack
 };
 
@@ -158,13 +168,19 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     bool fin = isfinite(r.inv.x) && isfinite(r.inv.y) && isfinite(r.inv.z) && isfinite(o.x) && isfinite(o.y) &&
                isfinite(o.z);
     r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
+    // Pruning compares a box's entry / exit t with hit t values.  A hit point and the faces
+    // of its leaf box agree only to eps ~ 1e-6 * scale in space (both come from f32 matrix
+    // products), which is eps * |1/d_i| in t along axis i: for a ray nearly parallel to a
+    // box face that is unbounded, and a box can "begin" after a hit that lies inside it (found
+    // by rays aimed at mesh vertices with one direction component ~1e-4).  Axes with
+    // |1/d_i| > ILL_INV are therefore left out of the entry t that pruning looks at (a
+    // normalised direction always keeps one axis with |1/d_i| <= 1.74; the centre row and
+    // column of every image are such rays), and such rays do not prune boxes behind the
+    // origin; slack0 covers eps * ILL_INV for the others.
+    r.ill = (!(fabsf(r.inv.x) <= ILL_INV) ? 1u : 0u) | (!(fabsf(r.inv.y) <= ILL_INV) ? 2u : 0u) |
+            (!(fabsf(r.inv.z) <= ILL_INV) ? 4u : 0u);
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    r.oi = f3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
-    r.delta0 = 2.4e-7f * fmaxf(fmaxf(fabsf(r.oi.x), fabsf(r.oi.y)), fabsf(r.oi.z));
-    // pruning compares slab t values (error <= 4u|t| + u|o*inv|, see slab_fast) with hit t
-    // values: the slack carries the absolute part of that error too -- for a ray nearly
-    // parallel to an axis |o*inv| is large and 1.5e-5*scale alone would be too tight
-    r.slack0 = 1.5e-5f * (sc.coord_scale + m) + r.delta0;
+    r.slack0 = RTX_SLACK * (sc.coord_scale + m);
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 
@@ -247,7 +263,7 @@ __device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float 
     }
     t_entry = tmin;
     if (!prune) return hit;
-    return hit && !(tmax < -r.slack0) && !(tmin > limit_plus);
+    return hit && !(r.ill == 0u && tmax < -r.slack0) && !(tmin > limit_plus);
 }
 
 // Object::get_intersection (object.rs:145-220) against one 64-byte primitive record.
@@ -369,19 +385,18 @@ __device__ __forceinline__ void cswap(float &ta, uint32_t &ra, float &tb, uint32
 // Reciprocal slab test of one box (not for exact_only rays): entry/exit t, `miss` when the
 // intervals are clearly separated, `sure` when they clearly overlap; anything else is
 // within the f32 error of the reference's division form and must be decided by box_exact.
-// One fused multiply-add per plane, p*inv - o*inv.  Against the reference's fl(fl(p - o) / d),
-// with u = 2^-24: inv and o*inv carry one rounding each, the fma one, the reference two, so a
-// plane differs by at most 4u|t| + u|o*inv| (+ O(u^2)); max/min of planes inherit the bound,
-// and two interval ends are decided only when they are further apart than
-// 2*(5u*max|t| + 2u*max|o*inv|) <= 7.2e-7*max|t| + delta0.
+// tprune: the entry t over the well-conditioned axes only (<= tmin), what pruning may use.
 __device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                          const RayCtx &r, float &tmin, float &tmax, bool &miss, bool &sure) {
-    float ax = __builtin_fmaf(mnx, r.inv.x, -r.oi.x), bx = __builtin_fmaf(mxx, r.inv.x, -r.oi.x);
-    float ay = __builtin_fmaf(mny, r.inv.y, -r.oi.y), by = __builtin_fmaf(mxy, r.inv.y, -r.oi.y);
-    float az = __builtin_fmaf(mnz, r.inv.z, -r.oi.z), bz = __builtin_fmaf(mxz, r.inv.z, -r.oi.z);
-    tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+                                          const RayCtx &r, float &tmin, float &tmax, bool &miss, bool &sure,
+                                          float &tprune) {
+    float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
+    float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
+    float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
+    float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
+    tmin = fmaxf(fmaxf(nx, ny), nz);
+    tprune = fmaxf(fmaxf((r.ill & 1u) ? -INFINITY : nx, (r.ill & 2u) ? -INFINITY : ny), (r.ill & 4u) ? -INFINITY : nz);
     tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    float delta = __builtin_fmaf(fmaxf(fabsf(tmin), fabsf(tmax)), 7.2e-7f, r.delta0);
+    float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
     miss = tmin > tmax + delta;
     sure = tmin <= tmax - delta;
 }
@@ -447,12 +462,16 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         }
         uint32_t r0 = __float_as_uint(rf4.x), r1 = __float_as_uint(rf4.y), r2 = __float_as_uint(rf4.z),
                  r3 = __float_as_uint(rf4.w);
-        float t0, t1, t2, t3, x0, x1, x2, x3;  // entry / exit t per slot
+        // per slot: entry t that pruning may use (well-conditioned axes only) / exit t
+        float t0, t1, t2, t3, x0, x1, x2, x3;
         bool m0, m1, m2, m3, s0, s1, s2, s3;
-        slab_fast(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, s.r, t0, x0, m0, s0);
-        slab_fast(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, s.r, t1, x1, m1, s1);
-        slab_fast(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, s.r, t2, x2, m2, s2);
-        slab_fast(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, s.r, t3, x3, m3, s3);
+        {
+            float e0, e1, e2, e3;  // full entry t: only decides miss / sure inside slab_fast
+            slab_fast(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, s.r, e0, x0, m0, s0, t0);
+            slab_fast(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, s.r, e1, x1, m1, s1, t1);
+            slab_fast(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, s.r, e2, x2, m2, s2, t2);
+            slab_fast(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, s.r, e3, x3, m3, s3, t3);
+        }
         // leaf slots inside the error band (and every slot of an exact_only ray) re-run the
         // reference's divisions; rare, so it sits behind ONE wave-uniform branch and reloads
         // the slot's box instead of keeping it live
@@ -468,12 +487,13 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
                 const float *nb = reinterpret_cast<const float *>(sc.wnodes + cur) + k;
                 const uint32_t rk = reinterpret_cast<const uint32_t *>(sc.wnodes + cur)[24 + k];
                 const float bx0 = nb[0], by0 = nb[4], bz0 = nb[8], bx1 = nb[12], by1 = nb[16], bz1 = nb[20];
-                float tk, xk;
+                float tk, xk, pk;
                 bool mk, sk;
-                slab_fast(bx0, by0, bz0, bx1, by1, bz1, s.r, tk, xk, mk, sk);
+                slab_fast(bx0, by0, bz0, bx1, by1, bz1, s.r, tk, xk, mk, sk, pk);
                 if ((eo & (rk != WIDE_EMPTY)) | (((int32_t)rk < -1) & !mk & !sk)) {
                     float a, b;
                     bool h = box_exact(bx0, by0, bz0, bx1, by1, bz1, s.r.o, s.r.d, a, b);
+                    if (s.r.ill != 0u) a = -INFINITY;  // the exact entry t is as ill-conditioned as the fast one
                     if (k == 0u) { k0 = h; t0 = a; x0 = b; }
                     if (k == 1u) { k1 = h; t1 = a; x1 = b; }
                     if (k == 2u) { k2 = h; t2 = a; x2 = b; }
@@ -482,7 +502,7 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
             }
         }
         // pruning: box behind the origin or beyond the best hit
-        const float back = -s.r.slack0, lim = s.limit_plus;
+        const float back = s.r.ill != 0u ? -INFINITY : -s.r.slack0, lim = s.limit_plus;
         bool h0 = k0 && !(x0 < back) && !(t0 > lim);
         bool h1 = k1 && !(x1 < back) && !(t1 > lim);
         bool h2 = k2 && !(x2 < back) && !(t2 > lim);
