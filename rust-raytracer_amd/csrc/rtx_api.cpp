@@ -61,6 +61,7 @@ struct rtx_ctx {
     uint32_t h_counter_slots = 0;
     std::vector<hipEvent_t> events;
     uint64_t node_budget_bytes = 32ull << 30;
+    uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
     uint64_t overlap_below = ~0ull;  // renders with fewer primary samples run their kernels concurrently (RTX_CONCURRENT=0: none)
 };
 
@@ -300,6 +301,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         c->err = "no scene uploaded";
         return RTX_ERR_NO_SCENE;
     }
+    flags |= c->force_flags;
     if (spp == 0) {
         c->err = "samples_per_pixel must be non-zero (world.rs:30)";
         return RTX_ERR_INVALID;
@@ -510,6 +512,8 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     c->stream = c->pipes[0].main;
     c->persistent_blocks = query_persistent_blocks(device);
+    if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
+        if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
     if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: never, 1: always
         c->overlap_below = std::atoi(ov) ? ~0ull : 0ull;
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
@@ -770,6 +774,7 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         return RTX_ERR_NO_SCENE;
     }
     if (n == 0) return RTX_OK;
+    flags |= c->force_flags;
     if (depth > 8) {
         c->err = "depth > 8 not supported";
         return RTX_ERR_CAPACITY;

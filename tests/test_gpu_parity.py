@@ -157,6 +157,36 @@ def test_grazing_rays_bit_exact(rt, orc, gpu, name, width, param):
     assert (obj_o != 0xFFFFFFFF).mean() > 0.3
 
 
+def test_grazing_rays_shaded_identically_by_both_traversals(rt, gpu, monkeypatch):
+    """World::trace_ray for rays aimed at mesh vertices (bounces and shadow rays start at
+    vertices and edges): the pruned traversal and the verbatim one (a second context forced to
+    it by RTX_REFERENCE_TRAVERSAL=1) share all shading code, so the colours must be identical
+    bit for bit -- this covers the any-hit shadow queries, which no hit-id API exposes."""
+    s = rt.HostScene("scan_glass", 32, 8000)
+    gpu.upload(s)
+    vw = _world_vertices(s)
+    rng = np.random.default_rng(23)
+    n = 12000
+    tgt = vw[rng.integers(0, len(vw), n)]
+    org = rng.uniform(-6, 6, (n, 3))
+    m = n // 3  # nearly axis-parallel
+    ax = rng.integers(0, 3, m)
+    off = rng.uniform(-5, 5, (m, 3))
+    off[np.arange(m), ax] = rng.uniform(-1e-3, 1e-3, m)
+    org[:m] = tgt[:m] - off
+    rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    c_p = gpu.shade_rays(rays, depth=4)
+    monkeypatch.setenv("RTX_REFERENCE_TRAVERSAL", "1")
+    ref = rt.Context(0)
+    try:
+        ref.upload(s)
+        c_r = ref.shade_rays(rays, depth=4)
+    finally:
+        ref.close()
+    assert np.array_equal(c_p.view(np.uint32), c_r.view(np.uint32))
+    assert (c_p.max(axis=1) > 0).mean() > 0.5
+
+
 def test_reference_bvh_known_answers_on_device(rt, gpu):
     """bvh.rs:494-540 (test_bvh_intersect) on the device."""
     from test_oracle_kat import BVH_OBJECTS, BVH_RAYS
