@@ -187,6 +187,30 @@ def test_grazing_rays_shaded_identically_by_both_traversals(rt, gpu, monkeypatch
     assert (c_p.max(axis=1) > 0).mean() > 0.5
 
 
+def test_degenerate_rays_match_oracle(rt, orc, gpu):
+    """Zero, NaN and infinite components (utils.rs refract yields NaN directions on total
+    internal reflection): both traversals and the oracle agree bit for bit."""
+    s, o = _pair(rt, orc, gpu, "basic_suzanne", 32, 0)
+    nan, inf = np.nan, np.inf
+    base = [0.3, 1.2, 4.0]
+    rays = np.array([
+        base + [0.0, 0.0, 0.0],            # zero direction: normalisation gives NaN
+        base + [nan, 0.0, -1.0], base + [0.0, nan, -1.0], base + [nan, nan, nan],
+        base + [inf, 0.0, -1.0], base + [0.0, -inf, -1.0], base + [inf, inf, inf],
+        [nan, 1.0, 4.0, 0.0, 0.0, -1.0], [inf, 1.0, 4.0, 0.0, 0.0, -1.0], [0.0, -inf, 4.0, 0.0, 0.1, -1.0],
+        base + [1e-30, 0.0, -1.0], base + [1e-38, 1e-38, -1.0], base + [-0.0, 0.0, -1.0],
+        base + [1e38, 1e38, -1e38], base + [1e-45, -1.0, 1e-45],   # overflow in the norm / denormals
+        [1e30, 1.0, 4.0, -1.0, 0.0, 0.0], [0.0, 1e20, 0.0, 0.0, -1.0, 0.0],
+        base + [0.0, -1.0, 0.0], base + [0.0, 0.0, -1.0], base + [1.0, 0.0, 0.0],
+    ], np.float32)
+    obj_o, t_o = o.trace_rays(rays)
+    for flags in (0, rt.FLAG_REFERENCE_TRAVERSAL):
+        obj_g, t_g = gpu.trace_rays(rays, flags=flags)
+        assert np.array_equal(obj_g, obj_o), (flags, obj_g, obj_o)
+        assert np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32)), (flags, t_g, t_o)
+    assert (obj_o != 0xFFFFFFFF).any() and (obj_o == 0xFFFFFFFF).any()
+
+
 def test_reference_bvh_known_answers_on_device(rt, gpu):
     """bvh.rs:494-540 (test_bvh_intersect) on the device."""
     from test_oracle_kat import BVH_OBJECTS, BVH_RAYS
