@@ -211,6 +211,49 @@ def test_degenerate_rays_match_oracle(rt, orc, gpu):
     assert (obj_o != 0xFFFFFFFF).any() and (obj_o == 0xFFFFFFFF).any()
 
 
+def test_tangent_rays_on_spheres_bit_exact(rt, orc, gpu):
+    """Rays tangent to spheres (the d^2 <= r^2 boundary of object.rs:150-166) and through the
+    faces of their bounding boxes, near and far, incl. nearly axis-parallel ones."""
+    s, o = _pair(rt, orc, gpu, "random_spheres", 32, 300)
+    d = s.desc.contents
+    n_obj = d.n_objects
+    typ = np.ctypeslib.as_array(d.obj_type, (n_obj,))
+    verts = np.ctypeslib.as_array(d.obj_verts, (n_obj, 12)).astype(np.float64)
+    xf = np.ctypeslib.as_array(d.obj_xform, (n_obj,))
+    mats = np.ctypeslib.as_array(d.xforms, (d.n_xforms, 32)).astype(np.float64)
+    cen, rad = [], []
+    for i in np.nonzero(typ == 0)[0]:
+        m = mats[xf[i], :16].reshape(4, 4).T
+        c = m @ np.append(verts[i, :3], 1.0)
+        cen.append(c[:3] / c[3])
+        rad.append(verts[i, 3] * np.linalg.norm(m[:3, 0]))
+    cen, rad = np.array(cen), np.array(rad)
+    rng = np.random.default_rng(31)
+    n = 24000
+    k = rng.integers(0, len(cen), n)
+    org = rng.uniform(-8, 8, (n, 3))
+    org[:, 1] = np.abs(org[:, 1]) + 0.2
+    org[n // 2:] *= 50.0
+    m = n // 6  # nearly axis-parallel tangents
+    ax = rng.integers(0, 3, m)
+    off = rng.uniform(-6, 6, (m, 3))
+    off[np.arange(m), ax] = rng.uniform(-1e-3, 1e-3, m)
+    org[:m] = cen[k[:m]] - off
+    to_c = cen[k] - org
+    perp = np.cross(to_c, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    # tangent point as seen from org: offset by r * (1 +- tiny) perpendicular to the line of sight
+    scale = 1.0 + rng.choice([-1e-6, -1e-7, 0.0, 1e-7, 1e-6], n)
+    tgt = cen[k] + perp * (rad[k] * scale)[:, None]
+    rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    obj_o, t_o = o.trace_rays(rays)
+    for flags in (0, rt.FLAG_REFERENCE_TRAVERSAL):
+        obj_g, t_g = gpu.trace_rays(rays, flags=flags)
+        assert np.array_equal(obj_g, obj_o)
+        assert np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    assert (obj_o != 0xFFFFFFFF).mean() > 0.3
+
+
 def test_reference_bvh_known_answers_on_device(rt, gpu):
     """bvh.rs:494-540 (test_bvh_intersect) on the device."""
     from test_oracle_kat import BVH_OBJECTS, BVH_RAYS
