@@ -143,7 +143,12 @@ struct RayCtx {
     F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
     uint32_t xf;
     bool exact_only;  // a zero / non-finite component: always take the division path
-    uint32_t ill;     // bit i: axis i is ill-conditioned for pruning (|1/d_i| > ILL_INV), see init_ray
+    // axis i is ill-conditioned for pruning when |1/d_i| > ILL_INV (see init_ray): derived from
+    // inv where needed, not kept in a register
+    __device__ __forceinline__ bool ill_x() const { return !(fabsf(inv.x) <= ILL_INV); }
+    __device__ __forceinline__ bool ill_y() const { return !(fabsf(inv.y) <= ILL_INV); }
+    __device__ __forceinline__ bool ill_z() const { return !(fabsf(inv.z) <= ILL_INV); }
+    __device__ __forceinline__ bool ill_any() const { return ill_x() || ill_y() || ill_z(); }
     float slack0;     // absolute pruning slack
 };
 
@@ -177,8 +182,7 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     // normalised direction always keeps one axis with |1/d_i| <= 1.74; the centre row and
     // column of every image are such rays), and such rays do not prune boxes behind the
     // origin; slack0 covers eps * ILL_INV for the others.
-    r.ill = (!(fabsf(r.inv.x) <= ILL_INV) ? 1u : 0u) | (!(fabsf(r.inv.y) <= ILL_INV) ? 2u : 0u) |
-            (!(fabsf(r.inv.z) <= ILL_INV) ? 4u : 0u);
+
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.slack0 = RTX_SLACK * (sc.coord_scale + m);
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
@@ -263,7 +267,7 @@ __device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float 
     }
     t_entry = tmin;
     if (!prune) return hit;
-    return hit && !(r.ill == 0u && tmax < -r.slack0) && !(tmin > limit_plus);
+    return hit && !(!r.ill_any() && tmax < -r.slack0) && !(tmin > limit_plus);
 }
 
 // Object::get_intersection (object.rs:145-220) against one 64-byte primitive record.
@@ -394,7 +398,7 @@ __device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float
     float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
     float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
     tmin = fmaxf(fmaxf(nx, ny), nz);
-    tprune = fmaxf(fmaxf((r.ill & 1u) ? -INFINITY : nx, (r.ill & 2u) ? -INFINITY : ny), (r.ill & 4u) ? -INFINITY : nz);
+    tprune = fmaxf(fmaxf(r.ill_x() ? -INFINITY : nx, r.ill_y() ? -INFINITY : ny), r.ill_z() ? -INFINITY : nz);
     tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
     miss = tmin > tmax + delta;
@@ -493,7 +497,7 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
                 if ((eo & (rk != WIDE_EMPTY)) | (((int32_t)rk < -1) & !mk & !sk)) {
                     float a, b;
                     bool h = box_exact(bx0, by0, bz0, bx1, by1, bz1, s.r.o, s.r.d, a, b);
-                    if (s.r.ill != 0u) a = -INFINITY;  // the exact entry t is as ill-conditioned as the fast one
+                    if (s.r.ill_any()) a = -INFINITY;  // the exact entry t is as ill-conditioned as the fast one
                     if (k == 0u) { k0 = h; t0 = a; x0 = b; }
                     if (k == 1u) { k1 = h; t1 = a; x1 = b; }
                     if (k == 2u) { k2 = h; t2 = a; x2 = b; }
@@ -502,7 +506,7 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
             }
         }
         // pruning: box behind the origin or beyond the best hit
-        const float back = s.r.ill != 0u ? -INFINITY : -s.r.slack0, lim = s.limit_plus;
+        const float back = s.r.ill_any() ? -INFINITY : -s.r.slack0, lim = s.limit_plus;
         bool h0 = k0 && !(x0 < back) && !(t0 > lim);
         bool h1 = k1 && !(x1 < back) && !(t1 > lim);
         bool h2 = k2 && !(x2 < back) && !(t2 > lim);
