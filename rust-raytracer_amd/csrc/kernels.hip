@@ -1195,15 +1195,16 @@ __global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr
     const F3 bg = f3(sc.background[0], sc.background[1], sc.background[2]);
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += nthreads) {
         uint32_t node = base + i;
+        // shade_forward left a link for every node of the level (misses: no child): the phase
+        // filter needs only those 8 bytes, not the ray
+        const uint2 lk = fr.link[node];
+        if (phase != RESOLVE_ALL && (phase == RESOLVE_PARENTS) != (lk.y != NO_PRIM)) continue;
         float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
         uint32_t prim = __float_as_uint(d4.w);
         F3 res;
         if (prim >= INVALID_PRIM) {
-            if (phase == RESOLVE_PARENTS) continue;
             res = prim == INVALID_PRIM ? f3(0.f, 0.f, 0.f) : bg;  // world.rs:127-130
         } else {
-            uint2 lk = fr.link[node];
-            if (phase != RESOLVE_ALL && (phase == RESOLVE_PARENTS) != (lk.y != NO_PRIM)) continue;
             F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
             F3 p = o + o4.w * d;
             PrimView pv = load_prim(sc.prims + prim);
