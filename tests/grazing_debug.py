@@ -1,7 +1,7 @@
 """Debug aid: the grazing-ray set of tests/test_gpu_parity.py on the small scan scene; prints
 every ray on which production traversal, on-device reference traversal and oracle disagree."""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # lives under tests/: it uses the oracle
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 rt = importlib.import_module("rust-raytracer_amd")
