@@ -1212,22 +1212,35 @@ __global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr
             F3 surface = texture_sample(sc, m, pv, p);  // material.rs:229-230
             F3 normal = f3(0.f, 0.f, 0.f);
             bool have_normal = false;
-            F3 acc[MAX_COMP_DEPTH];
+            // accumulator stack of the Composition fold (material.rs:129-143), depth <= 4, in
+            // registers: a dynamically indexed array would live in scratch memory
+            F3 acc0 = f3(0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
             int asp = 0;
             F3 val = f3(0.f, 0.f, 0.f);
             for (uint32_t k = 0; k < m.prog_count; k++) {
                 MatInstr ins = sc.prog[m.prog_first + k];
                 switch (ins.op) {
                     case OP_BEGIN:
-                        if (asp < MAX_COMP_DEPTH) acc[asp] = f3(0.f, 0.f, 0.f);
+                        if (asp == 0) acc0 = f3(0.f, 0.f, 0.f);
+                        else if (asp == 1) acc1 = f3(0.f, 0.f, 0.f);
+                        else if (asp == 2) acc2 = f3(0.f, 0.f, 0.f);
+                        else if (asp == 3) acc3 = f3(0.f, 0.f, 0.f);
                         asp++;
                         break;
-                    case OP_ITEM:
-                        if (asp >= 1 && asp <= MAX_COMP_DEPTH) acc[asp - 1] = cadd(acc[asp - 1], cscale(val, ins.p0));
+                    case OP_ITEM: {
+                        F3 term = cscale(val, ins.p0);
+                        if (asp == 1) acc0 = cadd(acc0, term);
+                        else if (asp == 2) acc1 = cadd(acc1, term);
+                        else if (asp == 3) acc2 = cadd(acc2, term);
+                        else if (asp == 4) acc3 = cadd(acc3, term);
                         break;
+                    }
                     case OP_END:
                         asp--;
-                        if (asp >= 0 && asp < MAX_COMP_DEPTH) val = acc[asp];
+                        if (asp == 0) val = acc0;
+                        else if (asp == 1) val = acc1;
+                        else if (asp == 2) val = acc2;
+                        else if (asp == 3) val = acc3;
                         break;
                     case OP_PHONG: {  // material.rs:144-184
                         if (!have_normal) {
