@@ -5,6 +5,8 @@ reference's f32 operations in order, so not even epsilon-ties are excused here);
 within 1/255 per channel on >= 99.9 % of pixels (libm calls -- atan2, acos, pow -- differ
 in the last ulp between glibc and the device library, which can flip a quantisation step).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -340,3 +342,19 @@ def test_errors(rt, gpu):
     gpu.upload(rt.ArrayScene([], width=16, height=16, background=(0.2, 0.2, 0.2)))
     img, st = gpu.render()
     assert (img == 51).all() and st.rays == 256
+
+
+def test_cli_renders_the_same_png(rt, gpu, tmp_path):
+    """rtx-render with the reference's flags (main.rs:26-77) writes the PNG that the library
+    renders for the same scene, size, samples and bounces (spp 1: no jitter involved)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "rtx-render")
+    out = str(tmp_path / "cli.png")
+    subprocess.check_call([exe, "-f", out, "-w", "96", "-s", "1", "-b", "3", "-t", "2", "--scene", "basic_suzanne",
+                           "--media", rt.MEDIA_DIR])
+    img_cli = rt.png_read(out)
+    s = rt.HostScene("basic_suzanne", 96)
+    gpu.upload(s)
+    img, _ = gpu.render(spp=1, bounces=3)
+    assert img_cli.shape == img.shape and np.array_equal(img_cli, img)
+    assert subprocess.call([exe, "--no-such-flag"], stderr=subprocess.DEVNULL) == 2
