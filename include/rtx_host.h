@@ -29,6 +29,9 @@ typedef struct rtx_host_scene rtx_host_scene;
  *                      param = total triangles (0 = 2,374,525)
  *   "scan_glass"       BASELINE config 4: same geometry, mirror+glass+Phong compositions
  *   "soup"             BASELINE config 5: param random triangles (0 = 20,000,000), 4 point lights
+ *   "mesh:<path>"      load_basic + the OBJ or PLY (ascii / binary) file at <path>, scaled to a largest
+ *                      extent of 1.6 and set on the floor (Object::new_mesh, object.rs:30-91, reads OBJ
+ *                      only; the headline render's Stanford scans are PLY); param = 1: gold half-mirror
  * Returns NULL on error (rtx_host_last_error()). */
 rtx_host_scene *rtx_scene_builtin(const char *name, uint32_t width, const char *media_dir, uint64_t param);
 const rtx_scene_desc *rtx_scene_get_desc(const rtx_host_scene *s);

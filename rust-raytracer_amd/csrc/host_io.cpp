@@ -3,6 +3,7 @@
 // libpng is not available in the image, so PNG is hand-written over zlib.
 #include <zlib.h>
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,189 @@ bool load_obj(const std::string &path, ObjMesh &out, std::string &err) {
         // vt, vn, o, g, s, usemtl, mtllib: ignored like object.rs:55-57 does
     }
     return true;
+}
+
+// ------------------------------------------------------------------ PLY
+// The format of the Stanford scans behind the reference's headline render (README.md:7;
+// bun_zipper.ply, dragon_vrip.ply, ...): ascii and binary (little / big endian), a `vertex`
+// element with x, y, z among its scalar properties, a `face` element with one index list.
+// Other elements and properties are skipped.
+namespace {
+struct PlyProp {
+    std::string name;
+    int type = 0;       // scalar type (value type of a list)
+    int count_type = -1;  // >= 0: list property
+};
+struct PlyElem {
+    std::string name;
+    size_t count = 0;
+    std::vector<PlyProp> props;
+};
+// 0 int8 1 uint8 2 int16 3 uint16 4 int32 5 uint32 6 float32 7 float64
+int ply_type(const std::string &t) {
+    static const char *names[8][2] = {{"char", "int8"},   {"uchar", "uint8"}, {"short", "int16"},  {"ushort", "uint16"},
+                                      {"int", "int32"},   {"uint", "uint32"}, {"float", "float32"}, {"double", "float64"}};
+    for (int i = 0; i < 8; i++)
+        if (t == names[i][0] || t == names[i][1]) return i;
+    return -1;
+}
+const int PLY_SIZE[8] = {1, 1, 2, 2, 4, 4, 4, 8};
+double ply_decode(const uint8_t *p, int type, bool big) {
+    uint8_t b[8];
+    int n = PLY_SIZE[type];
+    for (int i = 0; i < n; i++) b[i] = big ? p[n - 1 - i] : p[i];
+    switch (type) {
+        case 0: { int8_t v; std::memcpy(&v, b, 1); return v; }
+        case 1: return b[0];
+        case 2: { int16_t v; std::memcpy(&v, b, 2); return v; }
+        case 3: { uint16_t v; std::memcpy(&v, b, 2); return v; }
+        case 4: { int32_t v; std::memcpy(&v, b, 4); return v; }
+        case 5: { uint32_t v; std::memcpy(&v, b, 4); return v; }
+        case 6: { float v; std::memcpy(&v, b, 4); return v; }
+        default: { double v; std::memcpy(&v, b, 8); return v; }
+    }
+}
+}  // namespace
+
+bool load_ply(const std::string &path, ObjMesh &out, std::string &err) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) {
+        err = "cannot open " + path;
+        return false;
+    }
+    out.positions.clear();
+    out.polys.clear();
+    std::string line;
+    if (!std::getline(f, line) || line.substr(0, 3) != "ply") {
+        err = path + ": not a PLY file";
+        return false;
+    }
+    int format = -1;  // 0 ascii, 1 binary little endian, 2 binary big endian
+    std::vector<PlyElem> elems;
+    bool header_done = false;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ss(line);
+        std::string tag;
+        if (!(ss >> tag)) continue;
+        if (tag == "format") {
+            std::string fm;
+            ss >> fm;
+            format = fm == "ascii" ? 0 : fm == "binary_little_endian" ? 1 : fm == "binary_big_endian" ? 2 : -1;
+        } else if (tag == "element") {
+            PlyElem e;
+            ss >> e.name >> e.count;
+            elems.push_back(e);
+        } else if (tag == "property") {
+            if (elems.empty()) {
+                err = path + ": property before any element";
+                return false;
+            }
+            PlyProp pr;
+            std::string t;
+            ss >> t;
+            if (t == "list") {
+                std::string ct, vt;
+                ss >> ct >> vt >> pr.name;
+                pr.count_type = ply_type(ct);
+                pr.type = ply_type(vt);
+                if (pr.count_type < 0 || pr.count_type > 5) pr.type = -1;
+            } else {
+                pr.type = ply_type(t);
+                ss >> pr.name;
+            }
+            if (pr.type < 0) {
+                err = path + ": unsupported property type in '" + line + "'";
+                return false;
+            }
+            elems.back().props.push_back(pr);
+        } else if (tag == "end_header") {
+            header_done = true;
+            break;
+        }  // comment, obj_info: ignored
+    }
+    if (!header_done || format < 0) {
+        err = path + ": bad PLY header";
+        return false;
+    }
+    const bool big = format == 2;
+    std::vector<uint8_t> buf(8);
+    // reads one scalar of `type` (ascii: next token)
+    auto scalar = [&](int type, double &v) -> bool {
+        if (format == 0) return (bool)(f >> v);
+        if (!f.read(reinterpret_cast<char *>(buf.data()), PLY_SIZE[type])) return false;
+        v = ply_decode(buf.data(), type, big);
+        return true;
+    };
+    for (const PlyElem &e : elems) {
+        const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+        int ix = -1, iy = -1, iz = -1, ilist = -1;
+        for (size_t k = 0; k < e.props.size(); k++) {
+            const PlyProp &pr = e.props[k];
+            if (is_vertex && pr.count_type < 0) {
+                if (pr.name == "x") ix = (int)k;
+                if (pr.name == "y") iy = (int)k;
+                if (pr.name == "z") iz = (int)k;
+            }
+            if (is_face && pr.count_type >= 0 && ilist < 0 && (pr.name == "vertex_indices" || pr.name == "vertex_index")) ilist = (int)k;
+        }
+        if (is_vertex && (ix < 0 || iy < 0 || iz < 0)) {
+            err = path + ": vertex element without x, y, z";
+            return false;
+        }
+        if (is_face && ilist < 0) {
+            err = path + ": face element without a vertex_indices list";
+            return false;
+        }
+        if (is_vertex) out.positions.reserve(out.positions.size() + e.count * 3);
+        if (is_face) out.polys.reserve(out.polys.size() + e.count);
+        for (size_t i = 0; i < e.count; i++) {
+            float xyz[3] = {0, 0, 0};
+            std::vector<uint32_t> poly;
+            for (size_t k = 0; k < e.props.size(); k++) {
+                const PlyProp &pr = e.props[k];
+                double v;
+                if (pr.count_type < 0) {
+                    if (!scalar(pr.type, v)) goto truncated;
+                    if ((int)k == ix) xyz[0] = (float)v;
+                    if ((int)k == iy) xyz[1] = (float)v;
+                    if ((int)k == iz) xyz[2] = (float)v;
+                } else {
+                    if (!scalar(pr.count_type, v) || v < 0 || v > 1e6) goto truncated;
+                    size_t n = (size_t)v;
+                    for (size_t j = 0; j < n; j++) {
+                        if (!scalar(pr.type, v)) goto truncated;
+                        if ((int)k == ilist) {
+                            if (v < 0 || v >= (double)(out.positions.size() / 3)) {
+                                err = path + ": face index out of range";
+                                return false;
+                            }
+                            poly.push_back((uint32_t)v);
+                        }
+                    }
+                }
+            }
+            if (is_vertex) out.positions.insert(out.positions.end(), xyz, xyz + 3);
+            if (is_face) {
+                if (poly.size() < 3) {
+                    err = path + ": face with fewer than 3 vertices";
+                    return false;
+                }
+                out.polys.push_back(std::move(poly));
+            }
+        }
+    }
+    return true;
+truncated:
+    err = path + ": truncated or malformed PLY body";
+    return false;
+}
+
+// By file extension: .ply -> load_ply, anything else -> load_obj.
+bool load_mesh(const std::string &path, ObjMesh &out, std::string &err) {
+    std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : "";
+    for (auto &c : ext) c = (char)std::tolower((unsigned char)c);
+    return ext == ".ply" ? load_ply(path, out, err) : load_obj(path, out, err);
 }
 
 // ------------------------------------------------------------------ PNG

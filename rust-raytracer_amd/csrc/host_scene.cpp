@@ -101,7 +101,10 @@ Object Object::transform(const M4 &o2w) const {
 std::vector<Object> Object::new_mesh(const std::string &path, const M4 &object_to_world, Material m) {
     ObjMesh mesh;
     std::string err;
-    if (!load_obj(path, mesh, err)) throw std::runtime_error(err);
+    if (!load_mesh(path, mesh, err)) throw std::runtime_error(err);  // OBJ as in the reference, or PLY
+    return from_mesh(mesh, object_to_world, m);
+}
+std::vector<Object> Object::from_mesh(const ObjMesh &mesh, const M4 &object_to_world, Material m) {
     M4 inv;
     if (!m4_invert(object_to_world, inv)) throw std::runtime_error("mesh transform is not invertible");
     std::vector<Object> out;
@@ -546,6 +549,31 @@ void add_scan_scene(SceneArrays &s, const std::string &media, uint64_t total, bo
     for (int k = 0; k < 4; k++) add_scan_mesh(s, counts[k], (uint32_t)(k + 1), centers[k], radii[k], s.add_material(mats[k]), xf);
 }
 
+// A mesh file under the lights and floor of load_basic: scaled so that its largest extent is
+// 1.6, centred over (0, 0.3) in x/z and set on the floor plane y = -1.
+void add_mesh_scene(SceneArrays &s, const std::string &media, const std::string &path, uint64_t material) {
+    ObjMesh mesh;
+    std::string err;
+    if (!load_mesh(path, mesh, err)) throw std::runtime_error(err);
+    if (mesh.positions.empty() || mesh.polys.empty()) throw std::runtime_error(path + ": no faces");
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < mesh.positions.size(); i++) {
+        lo[i % 3] = std::min(lo[i % 3], mesh.positions[i]);
+        hi[i % 3] = std::max(hi[i % 3], mesh.positions[i]);
+    }
+    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0.0f) || !std::isfinite(ext)) throw std::runtime_error(path + ": degenerate bounding box");
+    float k = 1.6f / ext;
+    M4 o2w = m4_from_translation(v3(-0.5f * (lo[0] + hi[0]) * k, -1.0f - lo[1] * k, 0.3f - 0.5f * (lo[2] + hi[2]) * k)) *
+             m4_from_nonuniform_scale(k, k, k);
+    Material m = material == 1
+                     ? Material::make(MaterialType::Composition({{MaterialType::Reflective(), 0.5f}, {MaterialType::new_phong(0.5f, 0.5f, 6.0f), 0.5f}}),
+                                      TextureType::new_flat(Color::rgb(0.9f, 0.75f, 0.3f)))
+                     : Material::make(MaterialType::new_phong(0.7f, 0.3f, 8.0f), TextureType::new_flat(Color::grayscale(0.8f)));
+    add_all(s, load_basic(media));
+    for (const auto &o : Object::from_mesh(mesh, o2w, m)) s.add_object(o);
+}
+
 void add_soup_scene(SceneArrays &s, uint64_t n) {
     if (n == 0) n = 20000000ull;
     M4 id = m4_identity();
@@ -585,6 +613,10 @@ bool build_builtin(SceneArrays &s, const std::string &name, uint32_t width, cons
         add_soup_scene(s, param);
         // look into the cloud from outside it
         s.set_camera(Camera::make(width, width, v3(0.0f, 6.0f, 24.0f), v3(0, 0, 0), v3(0, 1, 0)));
+    } else if (name.rfind("mesh:", 0) == 0) {
+        // any OBJ / PLY file under the lights and floor of load_basic: mesh:<path>, scaled to
+        // fit a unit box and set on the floor (`param` = material: 0 grey Phong, 1 mirror mix)
+        add_mesh_scene(s, media, name.substr(5), param);
     } else {
         g_host_err = "unknown scene '" + name + "'";
         return false;

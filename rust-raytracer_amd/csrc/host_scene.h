@@ -73,6 +73,7 @@ struct Object {
     M4 object_to_world = m4_identity(), world_to_object = m4_identity();
     Material material;
     static std::vector<Object> new_mesh(const std::string &path, const M4 &object_to_world, Material m);  // 30-91
+    static std::vector<Object> from_mesh(const struct ObjMesh &mesh, const M4 &object_to_world, Material m);  // the object.rs:62-88 half of new_mesh
     static Object new_sphere(V3 center, float radius, Material m);                                      // 93-100
     static Object new_quad(V3 a, V3 b, V3 c, V3 d, Material m);                                          // 102-115
     static Object new_triangle(V3 a, V3 b, V3 c, Material m);                                            // 117-129
@@ -148,6 +149,9 @@ struct ObjMesh {
     std::vector<std::vector<uint32_t>> polys;    // 0-based position indices
 };
 bool load_obj(const std::string &path, ObjMesh &out, std::string &err);
+// Stanford PLY (ascii / binary, either endianness): vertex x y z + face index lists.
+bool load_ply(const std::string &path, ObjMesh &out, std::string &err);
+bool load_mesh(const std::string &path, ObjMesh &out, std::string &err);  // by extension: .ply, else OBJ
 bool png_read_rgb8(const std::string &path, Image &out, std::string &err);
 bool png_write_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *rgb, std::string &err);
 

@@ -358,3 +358,39 @@ def test_cli_renders_the_same_png(rt, gpu, tmp_path):
     img, _ = gpu.render(spp=1, bounces=3)
     assert img_cli.shape == img.shape and np.array_equal(img_cli, img)
     assert subprocess.call([exe, "--no-such-flag"], stderr=subprocess.DEVNULL) == 2
+
+
+def test_ply_mesh_scene_matches_oracle(rt, orc, gpu, tmp_path):
+    """A binary PLY (the Stanford scans' format, README.md:7) through mesh:<path>: a displaced
+    UV sphere of triangles with quad caps rows, traced and shaded like any other scene."""
+    import struct
+    nu, nv = 96, 48
+    rng = np.random.default_rng(11)
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0.15, np.pi - 0.15, nv)
+    r = 1.0 + 0.08 * rng.standard_normal((nv, nu))
+    pos = np.stack([r * np.sin(v)[:, None] * np.cos(u), r * np.cos(v)[:, None] + 0 * u, r * np.sin(v)[:, None] * np.sin(u)], -1)
+    pos = pos.reshape(-1, 3).astype(np.float32) * np.float32(17.0) + np.float32(40.0)   # the loader rescales and centres
+    faces = []
+    for j in range(nv - 1):
+        for i in range(nu):
+            a, b, c, d = j * nu + i, j * nu + (i + 1) % nu, (j + 1) * nu + (i + 1) % nu, (j + 1) * nu + i
+            faces += [[a, b, c, d]] if j % 8 == 0 else [[a, b, c], [a, c, d]]
+    path = tmp_path / "blob.ply"
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {len(pos)}\nproperty float x\nproperty float y\n"
+                 f"property float z\nelement face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n").encode())
+        f.write(pos.tobytes())
+        for fc in faces:
+            f.write(struct.pack("<B" + "i" * len(fc), len(fc), *fc))
+    for material in (0, 1):
+        s, o = _pair(rt, orc, gpu, f"mesh:{path}", 96, material)
+        assert s.n_objects == 5 + len(faces)
+        obj_o, t_o = o.trace_primary()
+        obj_g, t_g = gpu.trace_primary()
+        assert np.array_equal(obj_g, obj_o) and np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+        assert (obj_o >= 5).mean() > 0.05          # the mesh is in view
+        img_o, _ = o.render(spp=2, bounces=4, seed=1)
+        img_g, _ = gpu.render(spp=2, bounces=4, seed=1)
+        ok, frac, worst = _image_close(img_g, img_o)
+        assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"

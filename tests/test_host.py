@@ -162,6 +162,123 @@ def test_suzanne_obj_ingestion(rt):
     np.testing.assert_allclose(m[0].T @ m[1].T, np.eye(4), atol=1e-6)   # world_to_object is the inverse
 
 
+def _mesh_fixture():
+    """A small closed mesh with triangles and quads (a cube with two faces split)."""
+    rng = np.random.default_rng(3)
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32) * np.float32(0.37)
+    v += rng.uniform(-0.01, 0.01, v.shape).astype(np.float32)
+    faces = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]]
+    return v, faces
+
+
+def _write_ply(path, v, faces, fmt, extra=False):
+    """ascii / binary_little_endian / binary_big_endian; `extra` adds properties and an element to skip."""
+    import struct
+    e = {"binary_little_endian": "<", "binary_big_endian": ">"}.get(fmt)
+    head = ["ply", f"format {fmt} 1.0", "comment written by the test", f"element vertex {len(v)}"]
+    if extra:
+        head += ["property uchar red", "property float x", "property double y", "property float z", "property short q"]
+    else:
+        head += ["property float x", "property float y", "property float z"]
+    if extra:
+        head += ["element edge 2", "property int a", "property int b"]
+    head += [f"element face {len(faces)}"]
+    if extra:
+        head += ["property uchar flags"]
+    head += ["property list uchar int vertex_indices" if not extra else "property list ushort uint vertex_index", "end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        if e is None:
+            for p in v:
+                xyz = [repr(float(c)) for c in p]
+                f.write((" ".join((["200"] if extra else []) + xyz + (["-3"] if extra else [])) + "\n").encode())
+            if extra:
+                f.write(b"0 1\n1 2\n")
+            for fc in faces:
+                f.write((" ".join((["7"] if extra else []) + [str(len(fc))] + [str(i) for i in fc]) + "\n").encode())
+        else:
+            for p in v:
+                if extra:
+                    f.write(struct.pack(e + "Bfdfh", 200, p[0], float(p[1]), p[2], -3))
+                else:
+                    f.write(struct.pack(e + "fff", *p))
+            if extra:
+                f.write(struct.pack(e + "iiii", 0, 1, 1, 2))
+            for fc in faces:
+                if extra:
+                    f.write(struct.pack(e + "BH" + "I" * len(fc), 7, len(fc), *fc))
+                else:
+                    f.write(struct.pack(e + "B" + "i" * len(fc), len(fc), *fc))
+
+
+def _scene_arrays(scene):
+    d = scene.desc.contents   # `scene` stays referenced while its arrays are copied
+    n = d.n_objects
+    return (np.ctypeslib.as_array(d.obj_type, shape=(n,)).copy(), np.ctypeslib.as_array(d.obj_verts, shape=(n * 12,)).copy(),
+            np.ctypeslib.as_array(d.xforms, shape=(d.n_xforms * 32,)).copy())
+
+
+def test_ply_and_obj_ingestion_agree(rt, tmp_path):
+    """The same mesh as OBJ, ascii PLY and both binary PLY byte orders gives identical scene arrays
+    (README.md:7: the reference's headline scene is made of the Stanford .ply scans)."""
+    v, faces = _mesh_fixture()
+    obj = tmp_path / "m.obj"
+    with open(obj, "w") as f:
+        for p in v:
+            f.write("v " + " ".join(repr(float(c)) for c in p) + "\n")
+        for fc in faces:
+            f.write("f " + " ".join(str(i + 1) for i in fc) + "\n")
+    want = _scene_arrays(rt.HostScene(f"mesh:{obj}", 16))
+    assert (want[0] == 2).sum() == 4 + 1 and (want[0] == 1).sum() == 4 + 1 and (want[0] == 0).sum() == 3   # + load_basic
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        for extra in (False, True):
+            ply = tmp_path / f"m_{fmt}_{int(extra)}.PLY"
+            _write_ply(ply, v, faces, fmt, extra)
+            got = _scene_arrays(rt.HostScene(f"mesh:{ply}", 16))
+            for a, b in zip(want, got):
+                assert a.shape == b.shape and a.tobytes() == b.tobytes(), (fmt, extra)
+    # set on the floor y = -1 and scaled to a largest extent of 1.6: the world-space box of the mesh objects
+    s = rt.HostScene(f"mesh:{obj}", 16, 1)
+    d = s.desc.contents
+    assert d.n_materials == 6 and d.n_lights == 5
+    xf = np.ctypeslib.as_array(d.obj_xform, shape=(d.n_objects,))[-8:]
+    assert (xf == xf[0]).all()
+    m = np.ctypeslib.as_array(d.xforms, shape=(d.n_xforms, 2, 4, 4))[xf[0], 0].T.astype(np.float64)
+    ov = np.ctypeslib.as_array(d.obj_verts, shape=(d.n_objects, 4, 3))[-8:]
+    ty = np.ctypeslib.as_array(d.obj_type, shape=(d.n_objects,))[-8:]
+    pts = np.concatenate([ov[i, :(4 if ty[i] == 2 else 3)] for i in range(8)]).astype(np.float64)
+    w = pts @ m[:3, :3].T + m[:3, 3]
+    lo, hi = w.min(0), w.max(0)
+    assert abs(lo[1] + 1.0) < 1e-5 and abs((hi - lo).max() - 1.6) < 1e-5
+    assert abs(lo[0] + hi[0]) < 1e-5 and abs(0.5 * (lo[2] + hi[2]) - 0.3) < 1e-5
+
+
+def test_ply_errors_are_reported(rt, tmp_path):
+    v, faces = _mesh_fixture()
+    good = tmp_path / "g.ply"
+    _write_ply(good, v, faces, "binary_little_endian")
+    raw = good.read_bytes()
+    cases = {
+        "truncated.ply": raw[:-5],
+        "nomagic.ply": b"plx" + raw[3:],
+        "noheader.ply": raw[:40],
+        "badtype.ply": raw.replace(b"property float x", b"property half x"),
+        "nox.ply": raw.replace(b"property float x", b"property float u"),
+        "index.ply": raw[:-4] + (99).to_bytes(4, "little"),
+        "pentagon.ply": None,
+    }
+    for name, data in cases.items():
+        p = tmp_path / name
+        if data is None:
+            _write_ply(p, v, [[0, 1, 3, 2, 4]], "ascii")
+        else:
+            p.write_bytes(data)
+        with pytest.raises(rt.RtxError):
+            rt.HostScene(f"mesh:{p}", 16)
+    with pytest.raises(rt.RtxError):
+        rt.HostScene(f"mesh:{tmp_path / 'missing.ply'}", 16)
+
+
 def test_builtin_scene_inventory(rt):
     b = rt.HostScene("basic", 16).desc.contents
     assert (b.n_objects, b.n_lights, b.n_textures) == (5, 5, 1)
