@@ -571,7 +571,26 @@ void add_mesh_scene(SceneArrays &s, const std::string &media, const std::string 
                                       TextureType::new_flat(Color::rgb(0.9f, 0.75f, 0.3f)))
                      : Material::make(MaterialType::new_phong(0.7f, 0.3f, 8.0f), TextureType::new_flat(Color::grayscale(0.8f)));
     add_all(s, load_basic(media));
-    for (const auto &o : Object::from_mesh(mesh, o2w, m)) s.add_object(o);
+    // straight into the flat arrays: one transform and one material entry for the whole mesh,
+    // no per-polygon Object with two matrices and a material clone (object.rs:62-88 makes those)
+    M4 w2o;
+    if (!m4_invert(o2w, w2o)) throw std::runtime_error("mesh transform is not invertible");
+    const int xf = s.add_xform(o2w, w2o), mat = s.add_material(m);
+    const size_t n = mesh.polys.size();
+    s.obj_type.reserve(s.obj_type.size() + n);
+    s.obj_xform.reserve(s.obj_xform.size() + n);
+    s.obj_material.reserve(s.obj_material.size() + n);
+    s.obj_verts.reserve(s.obj_verts.size() + n * 12);
+    for (const auto &poly : mesh.polys) {
+        if (poly.size() != 3 && poly.size() != 4)  // object.rs:73-75 panics
+            throw std::runtime_error("Mesh has a polygon with " + std::to_string(poly.size()) + " vertices which is not supported.");
+        float v[12] = {0};
+        for (size_t k = 0; k < poly.size(); k++) std::memcpy(v + 3 * k, &mesh.positions[(size_t)poly[k] * 3], 12);
+        s.obj_type.push_back(poly.size() == 3 ? RTX_OBJ_TRIANGLE : RTX_OBJ_QUAD);
+        s.obj_verts.insert(s.obj_verts.end(), v, v + 12);
+        s.obj_xform.push_back(xf);
+        s.obj_material.push_back(mat);
+    }
 }
 
 void add_soup_scene(SceneArrays &s, uint64_t n) {
