@@ -242,6 +242,14 @@ int build_bvh(const rtx_scene_desc &d, int threads, BuiltBvh &out, std::string &
     out.depth = 0;
     if (n == 0) return RTX_OK;
     if (threads < 1) threads = 1;
+    // the boxes below index the transform table: reject bad indices before touching it
+    for (uint32_t i = 0; i < n; i++) {
+        int type = d.obj_type[i], xf = d.obj_xform[i];
+        if (type < 0 || type > 2 || xf < 0 || (uint32_t)xf >= d.n_xforms) {
+            err = "object with bad type / transform index";
+            return RTX_ERR_INVALID;
+        }
+    }
     Ctx c(d);
     c.boxes.resize(n);
     c.cents.resize(n);

@@ -240,9 +240,13 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         m.prog_count = (uint32_t)out.prog.size() - m.prog_first;
         m.n_bounce = nb;
         mat_bounce[i] = nb;
+        if (d.mat_tex_kind[i] < RTX_TEX_NONE || d.mat_tex_kind[i] > RTX_TEX_IMAGE) {
+            err = "unknown texture kind";
+            return RTX_ERR_INVALID;
+        }
         m.tex_kind = (uint32_t)d.mat_tex_kind[i];
         m.tex_id = (uint32_t)d.mat_tex_id[i];
-        if (m.tex_kind == RTX_TEX_IMAGE && m.tex_id >= d.n_textures) {
+        if (m.tex_kind == RTX_TEX_IMAGE && (d.mat_tex_id[i] < 0 || m.tex_id >= d.n_textures)) {
             err = "texture index out of range";
             return RTX_ERR_INVALID;
         }
@@ -270,6 +274,10 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
     out.lights.resize(d.n_lights);
     for (uint32_t i = 0; i < d.n_lights; i++) {
         LightRec &l = out.lights[i];
+        if (d.light_type[i] < RTX_LIGHT_AMBIENT || d.light_type[i] > RTX_LIGHT_CONE) {
+            err = "unknown light type";
+            return RTX_ERR_INVALID;
+        }
         l.type = (uint32_t)d.light_type[i];
         for (int k = 0; k < 3; k++) {
             l.pos[k] = d.light_pos[i * 3 + k];

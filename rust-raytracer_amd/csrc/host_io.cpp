@@ -3,6 +3,7 @@
 // libpng is not available in the image, so PNG is hand-written over zlib.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -197,8 +198,9 @@ bool load_ply(const std::string &path, ObjMesh &out, std::string &err) {
             err = path + ": face element without a vertex_indices list";
             return false;
         }
-        if (is_vertex) out.positions.reserve(out.positions.size() + e.count * 3);
-        if (is_face) out.polys.reserve(out.polys.size() + e.count);
+        const size_t plausible = std::min<size_t>(e.count, (size_t)1 << 26);  // a lying header must not reserve the world
+        if (is_vertex) out.positions.reserve(out.positions.size() + plausible * 3);
+        if (is_face) out.polys.reserve(out.polys.size() + plausible);
         for (size_t i = 0; i < e.count; i++) {
             float xyz[3] = {0, 0, 0};
             std::vector<uint32_t> poly;
@@ -308,6 +310,10 @@ bool png_read_rgb8(const std::string &path, Image &out, std::string &err) {
     }
     if (!have_ihdr || w == 0 || h == 0) {
         err = path + ": missing IHDR";
+        return false;
+    }
+    if (w > 65536u || h > 65536u || (uint64_t)w * h > (1ull << 28)) {
+        err = path + ": image dimensions out of range";
         return false;
     }
     if (depth != 8 || interlace != 0) {

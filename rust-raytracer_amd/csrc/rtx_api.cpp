@@ -19,7 +19,7 @@
 using namespace rtx;
 
 namespace {
-std::string g_init_error;
+thread_local std::string g_init_error;  // errors with no context to hold them (rtx_last_error(NULL))
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -88,6 +88,17 @@ int upload(rtx_ctx *c, const std::vector<T> &v, const T **out, std::vector<void 
     c->info.device_bytes += bytes;
     return RTX_OK;
 }
+
+// Device scratch of one call, released on every return path.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 256)); }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
 
 void free_all(std::vector<void *> &allocs) {
     for (void *p : allocs) (void)hipFree(p);
@@ -717,11 +728,13 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
     Pipe &pp = c->pipes[0];
     rc = ensure_frame(c, pp, chunk, 1);
     if (rc != RTX_OK) return rc;
+    flags |= c->force_flags;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
-    uint32_t *d_obj = nullptr;
-    float *d_t = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_obj, chunk * 4));
-    HIP_TRY(c, hipMalloc((void **)&d_t, chunk * 4));
+    DevBuf b_obj, b_t;
+    HIP_TRY(c, b_obj.alloc(chunk * 4));
+    HIP_TRY(c, b_t.alloc(chunk * 4));
+    uint32_t *d_obj = b_obj.as<uint32_t>();
+    float *d_t = b_t.as<float>();
     std::vector<uint32_t> h_obj(chunk);
     std::vector<float> h_t(chunk);
     int result = RTX_OK;
@@ -762,8 +775,6 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
             }
         }
     }
-    (void)hipFree(d_obj);
-    (void)hipFree(d_t);
     return result;
 }
 
@@ -786,11 +797,12 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
     int rc = ensure_frame(c, pp, chunk, std::max(levels, 1u));
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
-    float *d_rays = nullptr, *d_f = nullptr;
-    uint32_t *d_obj = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_rays, chunk * 24));
-    HIP_TRY(c, hipMalloc((void **)&d_f, chunk * 12));
-    HIP_TRY(c, hipMalloc((void **)&d_obj, chunk * 4));
+    DevBuf b_rays, b_f, b_obj;
+    HIP_TRY(c, b_rays.alloc(chunk * 24));
+    HIP_TRY(c, b_f.alloc(chunk * 12));
+    HIP_TRY(c, b_obj.alloc(chunk * 4));
+    float *d_rays = b_rays.as<float>(), *d_f = b_f.as<float>();
+    uint32_t *d_obj = b_obj.as<uint32_t>();
     int result = RTX_OK;
     for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
         uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - i0);
@@ -814,9 +826,6 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
             break;
         }
     }
-    (void)hipFree(d_rays);
-    (void)hipFree(d_f);
-    (void)hipFree(d_obj);
     return result;
 }
 

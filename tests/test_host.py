@@ -99,6 +99,18 @@ def test_degenerate_build_is_reported(rt):
     assert list(pre) == [4] and depth == 0 and n_int == 0
 
 
+def test_bad_object_indices_are_rejected(rt):
+    """A descriptor whose objects point outside the transform / material tables or carry an
+    unknown type is refused on the host, before anything is indexed with it."""
+    objs = [("sphere", (float(i), 0, 0), 0.4) for i in range(6)]
+    for field, bad in (("obj_xform", 7), ("obj_xform", -1), ("obj_type", 3), ("obj_type", -2), ("obj_material", 9)):
+        sc = rt.ArrayScene(objs)
+        getattr(sc, field)[3] = bad
+        with pytest.raises(rt.RtxError) as e:
+            rt.host_bvh_digest(sc)
+        assert e.value.status == rt.RTX_ERR_INVALID, field
+
+
 def test_empty_and_tiny_scenes(rt, orc):
     leaf, pre, depth, sa, n_int = rt.host_bvh_digest(rt.ArrayScene([]))
     assert len(leaf) == 0 and len(pre) == 0
