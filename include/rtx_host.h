@@ -26,7 +26,9 @@ typedef struct rtx_host_scene rtx_host_scene;
  *   "suzanne"          load_suzanne()                                  scene.rs:188-214
  *   "basic_suzanne"    BASELINE config 2: load_basic + load_suzanne + directional light
  *   "scan"             BASELINE config 3: load_basic + 4 synthetic scan-like meshes,
- *                      param = total triangles (0 = 2,374,525)
+ *                      param = total triangles (0 = 2,374,525).  With param = 0, each of
+ *                      dragon_vrip.ply / bun_zipper.ply / Armadillo.ply / happy_vrip.ply found in
+ *                      media_dir replaces its stand-in (same place, size and material)
  *   "scan_glass"       BASELINE config 4: same geometry, mirror+glass+Phong compositions
  *   "soup"             BASELINE config 5: param random triangles (0 = 20,000,000), 4 point lights
  *   "mesh:<path>"      load_basic + the OBJ or PLY (ascii / binary) file at <path>, scaled to a largest

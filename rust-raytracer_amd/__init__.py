@@ -127,6 +127,11 @@ def _ptr(a, typ):
     return a.ctypes.data_as(typ)
 
 
+# config 3's real inputs: Stanford scans that "scan" / "scan_glass" pick up from the media directory
+# when present (dragon, bunny, armadillo, Buddha -- the stand-ins' order)
+SCAN_FILES = ("dragon_vrip.ply", "bun_zipper.ply", "Armadillo.ply", "happy_vrip.ply")
+
+
 class HostScene:
     """A built-in scene (rtx_scene_builtin); .desc is the rtx_scene_desc pointer."""
 

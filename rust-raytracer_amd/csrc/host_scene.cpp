@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 
 #include "../../include/rtx_host.h"
@@ -517,8 +518,49 @@ void add_all(SceneArrays &s, const std::pair<std::vector<Object>, std::vector<Li
     for (const auto &l : ol.second) s.add_light(l);
 }
 
+// A loaded mesh straight into the flat arrays: one transform and one material entry for the
+// whole mesh, no per-polygon Object with two matrices and a material clone (object.rs:62-88
+// makes those).
+void add_mesh_flat(SceneArrays &s, const ObjMesh &mesh, const M4 &o2w, const Material &m) {
+    M4 w2o;
+    if (!m4_invert(o2w, w2o)) throw std::runtime_error("mesh transform is not invertible");
+    const int xf = s.add_xform(o2w, w2o), mat = s.add_material(m);
+    const size_t n = mesh.polys.size();
+    s.obj_type.reserve(s.obj_type.size() + n);
+    s.obj_xform.reserve(s.obj_xform.size() + n);
+    s.obj_material.reserve(s.obj_material.size() + n);
+    s.obj_verts.reserve(s.obj_verts.size() + n * 12);
+    for (const auto &poly : mesh.polys) {
+        if (poly.size() != 3 && poly.size() != 4)  // object.rs:73-75 panics
+            throw std::runtime_error("Mesh has a polygon with " + std::to_string(poly.size()) + " vertices which is not supported.");
+        float v[12] = {0};
+        for (size_t k = 0; k < poly.size(); k++) std::memcpy(v + 3 * k, &mesh.positions[(size_t)poly[k] * 3], 12);
+        s.obj_type.push_back(poly.size() == 3 ? RTX_OBJ_TRIANGLE : RTX_OBJ_QUAD);
+        s.obj_verts.insert(s.obj_verts.end(), v, v + 12);
+        s.obj_xform.push_back(xf);
+        s.obj_material.push_back(mat);
+    }
+}
+
+// Uniform scale + translation that gives the mesh a largest extent of `extent`, centres it
+// over (cx, cz) and sets its lowest point on y = floor_y.
+M4 fit_on_floor(const ObjMesh &mesh, float cx, float floor_y, float cz, float extent, const std::string &what) {
+    if (mesh.positions.empty() || mesh.polys.empty()) throw std::runtime_error(what + ": no faces");
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < mesh.positions.size(); i++) {
+        lo[i % 3] = std::min(lo[i % 3], mesh.positions[i]);
+        hi[i % 3] = std::max(hi[i % 3], mesh.positions[i]);
+    }
+    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0.0f) || !std::isfinite(ext)) throw std::runtime_error(what + ": degenerate bounding box");
+    float k = extent / ext;
+    return m4_from_translation(v3(cx - 0.5f * (lo[0] + hi[0]) * k, floor_y - lo[1] * k, cz - 0.5f * (lo[2] + hi[2]) * k)) *
+           m4_from_nonuniform_scale(k, k, k);
+}
+
 // Materials of the four stand-in meshes as they appear in media/scene.jpg: green, red and
 // green Phong, and a gold half-mirror.
+const char *const SCAN_FILES[4] = {"dragon_vrip.ply", "bun_zipper.ply", "Armadillo.ply", "happy_vrip.ply"};
 void add_scan_scene(SceneArrays &s, const std::string &media, uint64_t total, bool glass) {
     add_all(s, load_basic(media));
     if (total == 0) total = 2374525ull;
@@ -545,8 +587,29 @@ void add_scan_scene(SceneArrays &s, const std::string &media, uint64_t total, bo
     const float radii[4] = {0.55f, 0.3f, 0.45f, 0.65f};
     M4 id = m4_identity();
     int xf = s.add_xform(id, id);
-    reserve_tris(s, total);
-    for (int k = 0; k < 4; k++) add_scan_mesh(s, counts[k], (uint32_t)(k + 1), centers[k], radii[k], s.add_material(mats[k]), xf);
+    // the Stanford scans themselves when they lie in the media directory
+    // (they ship with neither the reference nor this repository); each one found replaces its
+    // stand-in, same place, size and material.  Only at the default triangle count.
+    ObjMesh real[4];
+    bool have[4] = {false, false, false, false};
+    uint64_t synthetic = 0;
+    for (int k = 0; k < 4; k++) {
+        const std::string path = media + "/" + SCAN_FILES[k];
+        std::string err;
+        if (total == 2374525ull && std::ifstream(path).good()) {
+            if (!load_mesh(path, real[k], err)) throw std::runtime_error(err);
+            have[k] = true;
+        } else {
+            synthetic += counts[k];
+        }
+    }
+    reserve_tris(s, synthetic);
+    for (int k = 0; k < 4; k++) {
+        if (have[k])
+            add_mesh_flat(s, real[k], fit_on_floor(real[k], centers[k].x, -1.0f, centers[k].z, 2.0f * radii[k], SCAN_FILES[k]), mats[k]);
+        else
+            add_scan_mesh(s, counts[k], (uint32_t)(k + 1), centers[k], radii[k], s.add_material(mats[k]), xf);
+    }
 }
 
 // A mesh file under the lights and floor of load_basic: scaled so that its largest extent is
@@ -555,42 +618,13 @@ void add_mesh_scene(SceneArrays &s, const std::string &media, const std::string 
     ObjMesh mesh;
     std::string err;
     if (!load_mesh(path, mesh, err)) throw std::runtime_error(err);
-    if (mesh.positions.empty() || mesh.polys.empty()) throw std::runtime_error(path + ": no faces");
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (size_t i = 0; i < mesh.positions.size(); i++) {
-        lo[i % 3] = std::min(lo[i % 3], mesh.positions[i]);
-        hi[i % 3] = std::max(hi[i % 3], mesh.positions[i]);
-    }
-    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-    if (!(ext > 0.0f) || !std::isfinite(ext)) throw std::runtime_error(path + ": degenerate bounding box");
-    float k = 1.6f / ext;
-    M4 o2w = m4_from_translation(v3(-0.5f * (lo[0] + hi[0]) * k, -1.0f - lo[1] * k, 0.3f - 0.5f * (lo[2] + hi[2]) * k)) *
-             m4_from_nonuniform_scale(k, k, k);
+    M4 o2w = fit_on_floor(mesh, 0.0f, -1.0f, 0.3f, 1.6f, path);
     Material m = material == 1
                      ? Material::make(MaterialType::Composition({{MaterialType::Reflective(), 0.5f}, {MaterialType::new_phong(0.5f, 0.5f, 6.0f), 0.5f}}),
                                       TextureType::new_flat(Color::rgb(0.9f, 0.75f, 0.3f)))
                      : Material::make(MaterialType::new_phong(0.7f, 0.3f, 8.0f), TextureType::new_flat(Color::grayscale(0.8f)));
     add_all(s, load_basic(media));
-    // straight into the flat arrays: one transform and one material entry for the whole mesh,
-    // no per-polygon Object with two matrices and a material clone (object.rs:62-88 makes those)
-    M4 w2o;
-    if (!m4_invert(o2w, w2o)) throw std::runtime_error("mesh transform is not invertible");
-    const int xf = s.add_xform(o2w, w2o), mat = s.add_material(m);
-    const size_t n = mesh.polys.size();
-    s.obj_type.reserve(s.obj_type.size() + n);
-    s.obj_xform.reserve(s.obj_xform.size() + n);
-    s.obj_material.reserve(s.obj_material.size() + n);
-    s.obj_verts.reserve(s.obj_verts.size() + n * 12);
-    for (const auto &poly : mesh.polys) {
-        if (poly.size() != 3 && poly.size() != 4)  // object.rs:73-75 panics
-            throw std::runtime_error("Mesh has a polygon with " + std::to_string(poly.size()) + " vertices which is not supported.");
-        float v[12] = {0};
-        for (size_t k = 0; k < poly.size(); k++) std::memcpy(v + 3 * k, &mesh.positions[(size_t)poly[k] * 3], 12);
-        s.obj_type.push_back(poly.size() == 3 ? RTX_OBJ_TRIANGLE : RTX_OBJ_QUAD);
-        s.obj_verts.insert(s.obj_verts.end(), v, v + 12);
-        s.obj_xform.push_back(xf);
-        s.obj_material.push_back(mat);
-    }
+    add_mesh_flat(s, mesh, o2w, m);
 }
 
 void add_soup_scene(SceneArrays &s, uint64_t n) {

@@ -265,6 +265,34 @@ def test_ply_and_obj_ingestion_agree(rt, tmp_path):
     assert abs(lo[0] + hi[0]) < 1e-5 and abs(0.5 * (lo[2] + hi[2]) - 0.3) < 1e-5
 
 
+def test_scan_scene_uses_stanford_files_when_present(rt, tmp_path):
+    """real scans lying in the media directory replace their stand-ins
+    (same place and size); here four small PLY files under the scans' names."""
+    import shutil
+    shutil.copy(os.path.join(rt.MEDIA_DIR, "texture.png"), tmp_path / "texture.png")
+    v, faces = _mesh_fixture()
+    for i, name in enumerate(rt.SCAN_FILES):
+        _write_ply(tmp_path / name, v * np.float32(1 + i), faces, ("ascii", "binary_little_endian", "binary_big_endian", "ascii")[i])
+    s = rt.HostScene("scan", 16, 0, media_dir=str(tmp_path))
+    d = s.desc.contents
+    assert d.n_objects == 5 + 4 * len(faces) and d.n_materials == 5 + 4
+    ov = np.ctypeslib.as_array(d.obj_verts, shape=(d.n_objects, 4, 3))
+    xf = np.ctypeslib.as_array(d.obj_xform, shape=(d.n_objects,))
+    xforms = np.ctypeslib.as_array(d.xforms, shape=(d.n_xforms, 2, 4, 4))
+    want = [((-0.9, 0.3), 0.55), ((0.0, 1.6), 0.3), ((2.5, 0.2), 0.45), ((-0.5, -1.3), 0.65)]   # stand-ins' centres / radii
+    for k, ((cx, cz), radius) in enumerate(want):
+        sl = slice(5 + k * len(faces), 5 + (k + 1) * len(faces))
+        m = xforms[xf[sl][0], 0].T.astype(np.float64)
+        pts = ov[sl].reshape(-1, 3).astype(np.float64)
+        pts = pts[np.abs(pts).sum(1) > 0]                      # the unused 4th vertex of triangles
+        w = pts @ m[:3, :3].T + m[:3, 3]
+        lo, hi = w.min(0), w.max(0)
+        assert abs(lo[1] + 1.0) < 1e-5 and abs((hi - lo).max() - 2 * radius) < 1e-5
+        assert abs(0.5 * (lo[0] + hi[0]) - cx) < 1e-5 and abs(0.5 * (lo[2] + hi[2]) - cz) < 1e-5
+    # a non-default triangle count always means the synthetic meshes
+    assert rt.HostScene("scan", 16, 2000, media_dir=str(tmp_path)).n_objects == 2005
+
+
 def test_ply_errors_are_reported(rt, tmp_path):
     v, faces = _mesh_fixture()
     good = tmp_path / "g.ply"
