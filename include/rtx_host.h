@@ -31,6 +31,8 @@ typedef struct rtx_host_scene rtx_host_scene;
  *                      media_dir replaces its stand-in (same place, size and material)
  *   "scan_glass"       BASELINE config 4: same geometry, mirror+glass+Phong compositions
  *   "soup"             BASELINE config 5: param random triangles (0 = 20,000,000), 4 point lights
+ *   "file:<path>"      a scene description file (camera, materials, objects, meshes, lights; the format
+ *                      is documented at the top of csrc/scene_file.cpp, example: assets/scenes/basic.scene)
  *   "mesh:<path>"      load_basic + the OBJ or PLY (ascii / binary) file at <path>, scaled to a largest
  *                      extent of 1.6 and set on the floor (Object::new_mesh, object.rs:30-91, reads OBJ
  *                      only; the headline render's Stanford scans are PLY); param = 1: gold half-mirror

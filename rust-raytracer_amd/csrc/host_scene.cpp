@@ -371,6 +371,31 @@ void SceneArrays::add_triangle(const float a[3], const float b[3], const float c
     obj_material.push_back(material);
 }
 
+// A loaded mesh straight into the flat arrays: one transform and one material entry for the
+// whole mesh, no per-polygon Object with two matrices and a material clone (object.rs:62-88
+// makes those).
+void SceneArrays::add_mesh(const ObjMesh &mesh, const M4 &o2w, const Material &m) {
+    SceneArrays &s = *this;
+    M4 w2o;
+    if (!m4_invert(o2w, w2o)) throw std::runtime_error("mesh transform is not invertible");
+    const int xf = s.add_xform(o2w, w2o), mat = s.add_material(m);
+    const size_t n = mesh.polys.size();
+    s.obj_type.reserve(s.obj_type.size() + n);
+    s.obj_xform.reserve(s.obj_xform.size() + n);
+    s.obj_material.reserve(s.obj_material.size() + n);
+    s.obj_verts.reserve(s.obj_verts.size() + n * 12);
+    for (const auto &poly : mesh.polys) {
+        if (poly.size() != 3 && poly.size() != 4)  // object.rs:73-75 panics
+            throw std::runtime_error("Mesh has a polygon with " + std::to_string(poly.size()) + " vertices which is not supported.");
+        float v[12] = {0};
+        for (size_t k = 0; k < poly.size(); k++) std::memcpy(v + 3 * k, &mesh.positions[(size_t)poly[k] * 3], 12);
+        s.obj_type.push_back(poly.size() == 3 ? RTX_OBJ_TRIANGLE : RTX_OBJ_QUAD);
+        s.obj_verts.insert(s.obj_verts.end(), v, v + 12);
+        s.obj_xform.push_back(xf);
+        s.obj_material.push_back(mat);
+    }
+}
+
 void SceneArrays::add_light(const Light &l) {
     light_type.push_back(l.type);
     light_pos.insert(light_pos.end(), {l.position.x, l.position.y, l.position.z});
@@ -518,30 +543,6 @@ void add_all(SceneArrays &s, const std::pair<std::vector<Object>, std::vector<Li
     for (const auto &l : ol.second) s.add_light(l);
 }
 
-// A loaded mesh straight into the flat arrays: one transform and one material entry for the
-// whole mesh, no per-polygon Object with two matrices and a material clone (object.rs:62-88
-// makes those).
-void add_mesh_flat(SceneArrays &s, const ObjMesh &mesh, const M4 &o2w, const Material &m) {
-    M4 w2o;
-    if (!m4_invert(o2w, w2o)) throw std::runtime_error("mesh transform is not invertible");
-    const int xf = s.add_xform(o2w, w2o), mat = s.add_material(m);
-    const size_t n = mesh.polys.size();
-    s.obj_type.reserve(s.obj_type.size() + n);
-    s.obj_xform.reserve(s.obj_xform.size() + n);
-    s.obj_material.reserve(s.obj_material.size() + n);
-    s.obj_verts.reserve(s.obj_verts.size() + n * 12);
-    for (const auto &poly : mesh.polys) {
-        if (poly.size() != 3 && poly.size() != 4)  // object.rs:73-75 panics
-            throw std::runtime_error("Mesh has a polygon with " + std::to_string(poly.size()) + " vertices which is not supported.");
-        float v[12] = {0};
-        for (size_t k = 0; k < poly.size(); k++) std::memcpy(v + 3 * k, &mesh.positions[(size_t)poly[k] * 3], 12);
-        s.obj_type.push_back(poly.size() == 3 ? RTX_OBJ_TRIANGLE : RTX_OBJ_QUAD);
-        s.obj_verts.insert(s.obj_verts.end(), v, v + 12);
-        s.obj_xform.push_back(xf);
-        s.obj_material.push_back(mat);
-    }
-}
-
 // Uniform scale + translation that gives the mesh a largest extent of `extent`, centres it
 // over (cx, cz) and sets its lowest point on y = floor_y.
 M4 fit_on_floor(const ObjMesh &mesh, float cx, float floor_y, float cz, float extent, const std::string &what) {
@@ -606,7 +607,7 @@ void add_scan_scene(SceneArrays &s, const std::string &media, uint64_t total, bo
     reserve_tris(s, synthetic);
     for (int k = 0; k < 4; k++) {
         if (have[k])
-            add_mesh_flat(s, real[k], fit_on_floor(real[k], centers[k].x, -1.0f, centers[k].z, 2.0f * radii[k], SCAN_FILES[k]), mats[k]);
+            s.add_mesh(real[k], fit_on_floor(real[k], centers[k].x, -1.0f, centers[k].z, 2.0f * radii[k], SCAN_FILES[k]), mats[k]);
         else
             add_scan_mesh(s, counts[k], (uint32_t)(k + 1), centers[k], radii[k], s.add_material(mats[k]), xf);
     }
@@ -624,7 +625,7 @@ void add_mesh_scene(SceneArrays &s, const std::string &media, const std::string 
                                       TextureType::new_flat(Color::rgb(0.9f, 0.75f, 0.3f)))
                      : Material::make(MaterialType::new_phong(0.7f, 0.3f, 8.0f), TextureType::new_flat(Color::grayscale(0.8f)));
     add_all(s, load_basic(media));
-    add_mesh_flat(s, mesh, o2w, m);
+    s.add_mesh(mesh, o2w, m);
 }
 
 void add_soup_scene(SceneArrays &s, uint64_t n) {
@@ -666,6 +667,10 @@ bool build_builtin(SceneArrays &s, const std::string &name, uint32_t width, cons
         add_soup_scene(s, param);
         // look into the cloud from outside it
         s.set_camera(Camera::make(width, width, v3(0.0f, 6.0f, 24.0f), v3(0, 0, 0), v3(0, 1, 0)));
+    } else if (name.rfind("file:", 0) == 0) {
+        // a scene description file (scene_file.cpp): what the reference does by editing main.rs:82-111
+        std::string err;
+        if (!load_scene_file(s, name.substr(5), width, media, err)) throw std::runtime_error(err);
     } else if (name.rfind("mesh:", 0) == 0) {
         // any OBJ / PLY file under the lights and floor of load_basic: mesh:<path>, scaled to
         // fit a unit box and set on the floor (`param` = material: 0 grey Phong, 1 mirror mix)

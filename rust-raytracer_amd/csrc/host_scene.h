@@ -130,6 +130,7 @@ struct SceneArrays {
     int add_material(const Material &m);           // interned by identity
     void add_object(const Object &o);
     void add_triangle(const float a[3], const float b[3], const float c[3], int xform, int material);
+    void add_mesh(const struct ObjMesh &mesh, const M4 &o2w, const Material &m);  // one transform + material entry for all polygons
     void add_light(const Light &l);
     void set_camera(const Camera &c);
     void set_background(Color c);
@@ -152,6 +153,9 @@ bool load_obj(const std::string &path, ObjMesh &out, std::string &err);
 // Stanford PLY (ascii / binary, either endianness): vertex x y z + face index lists.
 bool load_ply(const std::string &path, ObjMesh &out, std::string &err);
 bool load_mesh(const std::string &path, ObjMesh &out, std::string &err);  // by extension: .ply, else OBJ
+// Scene description file (scene_file.cpp documents the format): fills camera, background,
+// objects and lights; `width` is the -w default when the file has no `size` line.
+bool load_scene_file(SceneArrays &s, const std::string &path, uint32_t width, const std::string &media_dir, std::string &err);
 bool png_read_rgb8(const std::string &path, Image &out, std::string &err);
 bool png_write_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *rgb, std::string &err);
 

@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
                         "  -s, --samples_per_pixel N    Number of rays to cast per pixel [1]\n"
                         "  -b, --max_ray_bounces N      Max number of times to bounce a ray [4]\n"
                         "  -w, --pixel_width N          Width of the outputted image in pixels [500]\n"
-                        "      --scene NAME             basic|random_spheres|suzanne|basic_suzanne|scan|scan_glass|soup|mesh:FILE.obj|mesh:FILE.ply\n"
+                        "      --scene NAME             basic|random_spheres|suzanne|basic_suzanne|scan|scan_glass|soup|mesh:FILE.obj|mesh:FILE.ply|file:FILE.scene\n"
                         "      --media DIR, --param N, --device N\n");
             return 0;
         } else {

@@ -394,3 +394,18 @@ def test_ply_mesh_scene_matches_oracle(rt, orc, gpu, tmp_path):
         img_g, _ = gpu.render(spp=2, bounces=4, seed=1)
         ok, frac, worst = _image_close(img_g, img_o)
         assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
+
+
+def test_scene_file_renders_like_builtin(rt, gpu):
+    """assets/scenes/basic.scene describes load_basic; both ways of building the scene render
+    the same image, and hit ids / t agree bit for bit."""
+    a = rt.HostScene("basic", 96)
+    b = rt.HostScene("file:" + os.path.join(rt.MEDIA_DIR, "scenes", "basic.scene"), 96)
+    out = []
+    for s in (a, b):
+        gpu.upload(s)
+        obj, t = gpu.trace_primary()
+        img, _ = gpu.render(spp=2, bounces=4, seed=3)
+        out.append((obj, t, img))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert np.array_equal(out[0][2], out[1][2])

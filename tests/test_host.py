@@ -293,6 +293,69 @@ def test_scan_scene_uses_stanford_files_when_present(rt, tmp_path):
     assert rt.HostScene("scan", 16, 2000, media_dir=str(tmp_path)).n_objects == 2005
 
 
+def _desc_arrays(scene):
+    """Every array of an rtx_scene_desc as numpy copies, keyed by field name."""
+    d = scene.desc.contents
+    n = {"obj_type": d.n_objects, "obj_verts": d.n_objects * 12, "obj_xform": d.n_objects, "obj_material": d.n_objects,
+         "xforms": d.n_xforms * 32, "mat_root": d.n_materials, "mat_tex_kind": d.n_materials, "mat_tex_id": d.n_materials,
+         "mat_tex_color": d.n_materials * 3, "node_type": d.n_mat_nodes, "node_params": d.n_mat_nodes * 3,
+         "node_child_first": d.n_mat_nodes, "node_child_count": d.n_mat_nodes, "child_node": d.n_mat_children,
+         "child_coef": d.n_mat_children, "tex_w": d.n_textures, "tex_h": d.n_textures, "light_type": d.n_lights,
+         "light_pos": d.n_lights * 3, "light_dir": d.n_lights * 3, "light_angle_deg": d.n_lights, "light_color": d.n_lights * 3}
+    out = {k: np.ctypeslib.as_array(getattr(d, k), shape=(v,)).copy() for k, v in n.items() if v}
+    out["camera_to_world"] = np.array(list(d.camera_to_world), np.float32)
+    out["background"] = np.array(list(d.background), np.float32)
+    out["size"] = np.array([d.width, d.height])
+    return out
+
+
+def test_scene_file_reproduces_load_basic(rt):
+    """assets/scenes/basic.scene states scene.rs:11-108 + main.rs:108-111 in the scene-file
+    vocabulary; it must give the arrays of the built-in scene (+0 / -0 aside in the one
+    rotation-about-a-point matrix, which the built-in forms with an explicit inverse)."""
+    a = _desc_arrays(rt.HostScene("basic", 48))
+    b = _desc_arrays(rt.HostScene("file:" + os.path.join(rt.MEDIA_DIR, "scenes", "basic.scene"), 48))
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+
+
+def test_scene_file_statements_and_errors(rt, tmp_path):
+    v, faces = _mesh_fixture()
+    _write_ply(tmp_path / "m.ply", v, faces, "binary_little_endian")
+    ok = tmp_path / "ok.scene"
+    ok.write_text("""
+        size 40 24          # not square
+        shader s phong 0.5 0.5 2
+        texture t none
+        material m s t
+        mesh m m.ply  translate 0 1 0 scale 2 2 2 rotate_y 30
+        sphere m 0 0 0 1
+        light directional 0 -1 0  1 1 1
+    """)
+    s = rt.HostScene(f"file:{ok}", 64)
+    d = s.desc.contents
+    assert (d.width, d.height, d.n_objects, d.n_lights, d.n_materials, d.n_xforms) == (40, 24, len(faces) + 1, 1, 1, 2)
+    m = np.ctypeslib.as_array(d.xforms, shape=(d.n_xforms, 2, 4, 4))
+    np.testing.assert_allclose(m[0, 0].T @ m[0, 1].T, np.eye(4), atol=1e-6)
+    c, sn = np.cos(np.radians(30)), np.sin(np.radians(30))
+    want = np.array([[2 * c, 0, 2 * sn, 0], [0, 2, 0, 1], [-2 * sn, 0, 2 * c, 0], [0, 0, 0, 1]])
+    np.testing.assert_allclose(m[0, 0].T, want, atol=1e-6)
+    bad = {"frobnicate 1 2 3": "unknown statement", "sphere nope 0 0 0 1": "unknown material",
+           "shader a phong 1 x 1": "not a number", "light point 0 0 0 1 1": "missing", "texture t image missing.png": "",
+           "shader a mix 0.5 b": "unknown shader", "background 0 0 0 0": "unexpected",
+           "shader s none\ntexture t none\nmaterial m s t\nsphere m 0 0 0 1 spin 3": "unknown transform"}
+    for i, (text, msg) in enumerate(bad.items()):
+        p = tmp_path / f"bad{i}.scene"
+        p.write_text("# header\n" + text + "\n")
+        with pytest.raises(rt.RtxError) as e:
+            rt.HostScene(f"file:{p}", 16)
+        nline = 2 + text.count("\n")
+        assert f"bad{i}.scene:{nline}:" in str(e.value) and msg in str(e.value), str(e.value)
+    with pytest.raises(rt.RtxError):
+        rt.HostScene(f"file:{tmp_path / 'absent.scene'}", 16)
+
+
 def test_ply_errors_are_reported(rt, tmp_path):
     v, faces = _mesh_fixture()
     good = tmp_path / "g.ply"
