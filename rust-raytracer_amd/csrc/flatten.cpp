@@ -193,6 +193,71 @@ int emit_material(const rtx_scene_desc &d, int node, int depth, std::vector<MatI
 
 }  // namespace
 
+// The reference tests an object only when the ray passes its bounding box, but two kinds of
+// object can be HIT outside that box, and the production traversal's pruning (which compares
+// box entry / exit t with hit t) has to know by how much:
+//  * a quad is bounded by its four vertices (object.rs:284-299) but intersected on the plane
+//    through a with normal (b-a)x(d-a), inside the four edges seen along that normal
+//    (object.rs:167-189): a non-planar quad's region reaches to the projection c' of c onto
+//    that plane, which can lie outside the vertices' box;
+//  * a sphere is bounded by centre +- radius * |M e_k| (column norms, utils.rs:33-44), while the
+//    transformed sphere extends radius * |row_k(M)| along world axis k: different as soon as
+//    a rotation meets a non-uniform scale.
+// Returns the largest such excess over the objects, in world units (0 for triangles, planar
+// quads, spheres under rotation + uniform scale: every scene of scene.rs except Suzanne's
+// slightly non-planar quads); infinity when a transform is not affine.
+float hit_overhang(const rtx_scene_desc &d) {
+    double worst = 0.0;
+    for (uint32_t o = 0; o < d.n_objects; o++) {
+        const int type = d.obj_type[o];
+        if (type == RTX_OBJ_TRIANGLE) continue;
+        const float *v = d.obj_verts + (size_t)o * 12;
+        const float *M = d.xforms + (size_t)d.obj_xform[o] * 32;  // column-major object_to_world
+        if (M[3] != 0.0f || M[7] != 0.0f || M[11] != 0.0f || M[15] != 1.0f) return INFINITY;
+        auto world = [&](const double p[3], double w[3]) {
+            for (int k = 0; k < 3; k++) w[k] = (double)M[k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
+        };
+        float mn[3], mx[3];
+        object_bounding_box(d, o, mn, mx);
+        double excess = 0.0;
+        if (type == RTX_OBJ_SPHERE) {
+            for (int k = 0; k < 3; k++) {
+                double row = std::sqrt((double)M[k] * M[k] + (double)M[4 + k] * M[4 + k] + (double)M[8 + k] * M[8 + k]);
+                double c[3] = {v[0], v[1], v[2]}, wc[3];
+                world(c, wc);
+                excess = std::max(excess, std::max(wc[k] + std::fabs((double)v[3]) * row - (double)mx[k],
+                                                   (double)mn[k] - (wc[k] - std::fabs((double)v[3]) * row)));
+            }
+            // rounding of the box itself is not an overhang
+            if (excess < 4e-7 * (std::fabs((double)v[3]) + std::fabs((double)mx[0]) + std::fabs((double)mx[1]) + std::fabs((double)mx[2]))) excess = 0.0;
+        } else {
+            double a[3], b[3], c[3], e[3], n[3];
+            for (int k = 0; k < 3; k++) {
+                a[k] = v[k];
+                b[k] = v[3 + k];
+                c[k] = v[6 + k];
+                e[k] = v[9 + k];
+            }
+            const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {e[0] - a[0], e[1] - a[1], e[2] - a[2]};
+            n[0] = u[1] * w[2] - u[2] * w[1];
+            n[1] = u[2] * w[0] - u[0] * w[2];
+            n[2] = u[0] * w[1] - u[1] * w[0];
+            const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(len > 0.0)) continue;  // degenerate normal: the NaN normal never reports a hit
+            const double off = ((c[0] - a[0]) * n[0] + (c[1] - a[1]) * n[1] + (c[2] - a[2]) * n[2]) / len;
+            double cp[3] = {c[0] - off * n[0] / len, c[1] - off * n[1] / len, c[2] - off * n[2] / len}, wcp[3];
+            world(cp, wcp);
+            for (int k = 0; k < 3; k++) excess = std::max(excess, std::max(wcp[k] - (double)mx[k], (double)mn[k] - wcp[k]));
+            double size = 0.0;
+            for (int k = 0; k < 3; k++) size = std::max(size, std::max(std::fabs((double)mn[k]), std::fabs((double)mx[k])));
+            if (excess < 4e-7 * size) excess = 0.0;  // a planar quad: f32 rounding of the vertices only
+        }
+        if (!(excess <= worst)) worst = excess;  // NaN propagates to "no pruning"
+    }
+    if (!(worst == worst)) return INFINITY;
+    return worst == 0.0 ? 0.0f : (float)(worst * 1.0001 + 1e-7);
+}
+
 int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err) {
     out = FlatScene();
     if (d.n_xforms == 0 || d.n_xforms > 8192) {
@@ -323,6 +388,7 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         p.meta = (uint32_t)type | ((uint32_t)xf << 2) | (xf_identity[xf] ? 0x8000u : 0u) | ((uint32_t)mat << 16);
         if (mat_bounce[mat] > out.max_bounce) out.max_bounce = mat_bounce[mat];
     }
+    out.overhang = hit_overhang(d);
     // tree
     if (!bvh.nodes.empty()) {
         Emit e{bvh, out};

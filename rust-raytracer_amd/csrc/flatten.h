@@ -28,6 +28,7 @@ struct FlatScene {
     bool xf0_identity = false;          // transform 0 is exactly the identity matrix pair
     uint32_t max_bounce = 0;            // largest number of bounce leaves of any material in use
     float total_sa = 0.0f;              // BvhTree::total_sa (bvh.rs:419-426)
+    float overhang = 0.0f;              // how far a hit point can lie outside its object's reference box (flatten.cpp)
 };
 
 int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err);

@@ -25,6 +25,7 @@ struct DeviceScene {
     uint32_t xf0_identity;      // transform 0 is exactly the identity
     float root_mn[3], root_mx[3];
     float coord_scale;          // largest |coordinate| of the root box (pruning slack)
+    float overhang;             // largest distance by which a hit can lie outside its object's box (0 for most scenes)
     float background[3];
     float c2w[16];
     uint32_t width, height;

@@ -185,6 +185,20 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
 
     float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     r.slack0 = RTX_SLACK * (sc.coord_scale + m);
+    // Pruning also equates the slab parameter t with the distance that a hit reports, which
+    // holds for |d| = 1.  Ray::new's normalisation loses that for directions whose squared
+    // length leaves the normal f32 range (|d| ~ 1e-23: the dot product is a denormal with a
+    // few bits; |d| ~ 1e20: it overflows): such a ray prunes nothing -- an infinite slack
+    // turns every pruning comparison off -- and visits what the reference visits.
+    if (!(fabsf(dot(d, d) - 1.0f) <= 4e-6f)) r.slack0 = INFINITY;
+    // A hit can lie up to sc.overhang outside its object's box in space (non-planar quads,
+    // sheared spheres: flatten.cpp, hit_overhang), which is overhang * |1/d_i| in t on the
+    // axis that decides the box's entry or exit; the ill-conditioned axes are not looked at.
+    if (sc.overhang != 0.0f) {  // scene constant: uniform branch, skipped by most scenes
+        float g = fmaxf(fmaxf(r.ill_x() ? 0.0f : fabsf(r.inv.x), r.ill_y() ? 0.0f : fabsf(r.inv.y)),
+                        r.ill_z() ? 0.0f : fabsf(r.inv.z));
+        r.slack0 += sc.overhang * g;
+    }
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 

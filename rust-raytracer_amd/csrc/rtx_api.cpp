@@ -617,6 +617,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
         ds.background[k] = bgc < 0.0f ? 0.0f : (bgc > 1.0f ? 1.0f : bgc);
     }
     ds.coord_scale = scale;
+    ds.overhang = fs.overhang;
     std::memcpy(ds.c2w, d->camera_to_world, sizeof(ds.c2w));
     ds.width = d->width;
     ds.height = d->height;

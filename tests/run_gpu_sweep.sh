@@ -1,14 +1,10 @@
-# GPU box: A/B of kernel variants in gpurun_variants/ (built by tools/build_variant.sh):
-# headline bench line per variant.
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# Exactness sweep at scale (tools/exactness_sweep.py) over the scene kinds; one line per repetition.
+set -e
 mkdir -p gpurun_out
-for f in gpurun_variants/*.so; do
-  echo "== $f"
-  RTX_LIB=$GRAFT_REPO_ROOT/$f timeout -k 10 120 python -u bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j = json.loads(l); r = j['roofline']
-        print(j['value'], 'Mrays/s', j['ms_per_step'], 'ms/step, trace span', r['avg_launch_ms'])
-" || exit 1
+: > gpurun_out/sweep.log
+for spec in "scan 0 1 6" "soup 2000000 2 4" "basic_suzanne 0 3 4" "random_spheres 1000 4 4" "scan_glass 300000 5 3"; do
+  set -- $spec
+  timeout -k 10 280 python -u tools/exactness_sweep.py $1 $2 $3 $4 >> gpurun_out/sweep.log 2>&1
 done
+tail -40 gpurun_out/sweep.log

@@ -213,6 +213,72 @@ def test_degenerate_rays_match_oracle(rt, orc, gpu):
     assert (obj_o != 0xFFFFFFFF).any() and (obj_o == 0xFFFFFFFF).any()
 
 
+@pytest.mark.parametrize("name,width,param", [("basic_suzanne", 32, 0), ("scan", 32, 20000)])
+def test_direction_scales_bit_exact(rt, orc, gpu, name, width, param):
+    """Directions of every magnitude from 1e-30 to 1e30 aimed at vertices.  Around 1e-23 the
+    squared length is a denormal, Ray::new's normalisation returns a direction that is not
+    unit length, and the slab parameter stops being a distance: such rays must not prune."""
+    s, o = _pair(rt, orc, gpu, name, width, param)
+    vw = _world_vertices(s)
+    rng = np.random.default_rng(23)
+    n = 60000
+    tgt = vw[rng.integers(0, len(vw), n)]
+    org = rng.uniform(-12, 12, (n, 3))
+    scale = 10.0 ** rng.uniform(-30, 30, (n, 1))
+    scale[: n // 2] = 10.0 ** rng.uniform(-24.5, -18.5, (n // 2, 1))     # the denormal band of the squared length
+    rays = np.concatenate([org, (tgt - org) * scale], axis=1).astype(np.float32)
+    obj_o, t_o = o.trace_rays(rays)
+    for flags in (0, rt.FLAG_REFERENCE_TRAVERSAL):
+        obj_g, t_g = gpu.trace_rays(rays, flags=flags)
+        assert np.array_equal(obj_g, obj_o), f"flags {flags}: {(obj_g != obj_o).sum()} hit ids differ"
+        assert np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    assert (obj_o != 0xFFFFFFFF).mean() > 0.3
+
+
+def test_hits_outside_their_boxes_bit_exact(rt, orc, gpu):
+    """Objects that the reference can hit OUTSIDE the box it bounds them with: non-planar quads
+    (hit region = the quad seen along (b-a)x(d-a), reaching the projection of c) and spheres
+    under rotation + non-uniform scale (box from column norms).  Pruning by box entry t has to
+    allow for that overhang; found by a sweep: a ray aimed at a Suzanne vertex returned the
+    second-nearest polygon."""
+    rng = np.random.default_rng(5)
+    objs = []
+    g = 14
+    grid = np.stack(np.meshgrid(np.arange(g + 1), np.arange(g + 1), indexing="ij"), -1).astype(np.float64)
+    h = rng.uniform(-0.45, 0.45, (g + 1, g + 1))           # strongly non-planar quads of a height field
+    P = np.concatenate([(grid - g / 2) * 0.5, h[..., None]], -1)[..., [0, 2, 1]]     # y up
+    for layer in range(3):                                  # stacked sheets: competing hits close in t
+        for i in range(g):
+            for j in range(g):
+                a, b, c, d = P[i, j], P[i, j + 1], P[i + 1, j + 1], P[i + 1, j]
+                off = np.array([0, 0.35 * layer, 0])
+                objs.append(("quad", a + off, d + off, c + off, b + off, 0, layer % 2))
+    c30, s30 = np.cos(0.6), np.sin(0.6)
+    rot = np.array([[c30, -s30, 0, 0], [s30, c30, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    shear = rot @ np.diag([3.0, 0.4, 1.0, 1.0]) @ rot.T @ np.array([[1, 0, 0, 0.2], [0, 1, 0, 0.1], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    for k in range(40):
+        objs.append(("sphere", rng.uniform(-1.0, 1.0, 3), rng.uniform(0.05, 0.3), 0, 1))
+    xforms = [(np.eye(4), np.eye(4)), (shear, np.linalg.inv(shear))]
+    s = rt.ArrayScene(objs, width=48, height=48, xforms=xforms)
+    gpu.upload(s)
+    o = orc.Scene(s)
+    n = 120000
+    tgt = rng.uniform(-3.5, 3.5, (n, 3)) * np.array([1, 0.4, 1])
+    org = rng.uniform(-9, 9, (n, 3))
+    org[: n // 2, 1] = np.abs(org[: n // 2, 1]) + 1.0      # from above: quads face up or down, both are covered
+    rays = np.concatenate([org, tgt - org], axis=1).astype(np.float32)
+    obj_o, t_o = o.trace_rays(rays)
+    for flags in (0, rt.FLAG_REFERENCE_TRAVERSAL):
+        obj_g, t_g = gpu.trace_rays(rays, flags=flags)
+        assert np.array_equal(obj_g, obj_o), f"flags {flags}: {(obj_g != obj_o).sum()} hit ids differ"
+        assert np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    hit = obj_o != 0xFFFFFFFF
+    assert hit.mean() > 0.2 and (obj_o[hit] >= 3 * g * g).any() and (obj_o[hit] < 3 * g * g).any()
+    img_o, _ = o.render(spp=1, bounces=2, seed=1)
+    img_g, _ = gpu.render(spp=1, bounces=2, seed=1)
+    assert _image_close(img_g, img_o)[0]
+
+
 def test_tangent_rays_on_spheres_bit_exact(rt, orc, gpu):
     """Rays tangent to spheres (the d^2 <= r^2 boundary of object.rs:150-166) and through the
     faces of their bounding boxes, near and far, incl. nearly axis-parallel ones."""
