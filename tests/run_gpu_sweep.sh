@@ -5,6 +5,6 @@ mkdir -p gpurun_out
 : > gpurun_out/sweep.log
 for spec in "scan 0 1 6" "soup 2000000 2 4" "basic_suzanne 0 3 4" "random_spheres 1000 4 4" "scan_glass 300000 5 3"; do
   set -- $spec
-  timeout -k 10 280 python -u tools/exactness_sweep.py $1 $2 $3 $4 >> gpurun_out/sweep.log 2>&1
+  timeout -k 10 400 python -u tools/exactness_sweep.py $1 $2 $3 $4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
 done
 tail -40 gpurun_out/sweep.log

@@ -21,6 +21,14 @@ n = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
 gpu = rt.Context(0)
 s = rt.HostScene(scene, 64, param)
 gpu.upload(s)
+# shading check: World::trace_ray colours (bounces and any-hit shadow queries included) from a
+# second context that runs the verbatim traversal everywhere; same shading code, so bit-equal
+SHADE = os.environ.get("SWEEP_SHADE", "1") != "0"
+if SHADE:
+    os.environ["RTX_REFERENCE_TRAVERSAL"] = "1"
+    gref = rt.Context(0)
+    del os.environ["RTX_REFERENCE_TRAVERSAL"]
+    gref.upload(s)
 d = s.desc.contents
 N = d.n_objects
 typ = np.ctypeslib.as_array(d.obj_type, (N,))
@@ -132,11 +140,23 @@ for rep in range(reps):
     obj_g, t_g = gpu.trace_rays(rays)
     obj_r, t_r = gpu.trace_rays(rays, flags=rt.FLAG_REFERENCE_TRAVERSAL)
     diff = (obj_g != obj_r) | (t_g.view(np.uint32) != t_r.view(np.uint32))
+    if SHADE:
+        k = len(rays) // 4            # a quarter of every family (the verbatim traversal shades slowly)
+        sub = rays.reshape(8, m, 6)[:, : m // 4].reshape(-1, 6)
+        c_p = gpu.shade_rays(sub, depth=3)
+        c_r = gref.shade_rays(sub, depth=3)
+        cd = (c_p.view(np.uint32) != c_r.view(np.uint32)).any(axis=1)
+        sdiff = np.zeros(len(rays), bool)
+        sdiff.reshape(8, m)[:, : m // 4] = cd.reshape(8, m // 4)
+        diff = diff | sdiff
+        shade_note = f" shaded {len(sub)} colour mismatches {int(cd.sum())}"
+    else:
+        shade_note = ""
     bad += int(diff.sum())
     total += len(rays)
     hits = obj_r != 0xFFFFFFFF
     per = " ".join(f"{k}:{int(diff[fam == k].sum())}/{hits[fam == k].mean():.2f}" for k in range(8))
-    print(f"rep {rep}: {len(rays)} rays, mismatches {int(diff.sum())}   family:mismatches/hit-fraction {per}", flush=True)
+    print(f"rep {rep}: {len(rays)} rays,{shade_note} mismatches {int(diff.sum())}   family:mismatches/hit-fraction {per}", flush=True)
     if diff.any():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", f"sweep_mismatch_{scene.replace('/', '_').replace(':', '_')}.txt"), "a") as f:
