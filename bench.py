@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
-    ap.add_argument("--cpu-row-stride", type=int, default=2, help="oracle traces every n-th image row")
+    ap.add_argument("--cpu-row-stride", type=int, default=1, help="oracle traces every n-th image row (1: the whole frame, ~10 s of CPU work)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -180,7 +180,7 @@ def main():
         _, cst = o.render(spp=args.spp, bounces=args.bounces, seed=1, threads=threads,
                           region=(0, args.width, 1, 0, args.width, ys))
         cpu = {"value": round(cst.rays / cst.trace_seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": f"every {ys}. row of the same {args.width}x{args.width} {args.spp}-spp frame "
+               "sample": (f"every {ys}. row of the same" if ys > 1 else "one whole") + f" {args.width}x{args.width} {args.spp}-spp frame "
                          f"({cst.rays} rays in {cst.trace_seconds:.1f} s; oracle BVH build {cst.build_seconds:.1f} s extra)"}
         o.close()
 
