@@ -7,4 +7,7 @@ for spec in "scan 0 1 6" "soup 2000000 2 4" "basic_suzanne 0 3 4" "random_sphere
   set -- $spec
   timeout -k 10 400 python -u tools/exactness_sweep.py $1 $2 $3 $4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
 done
-tail -40 gpurun_out/sweep.log
+# objects that can be hit outside their boxes (non-planar quads, sheared spheres), through a scene file
+python tools/make_warped_scene.py gpurun_out/warped.scene 40 9 >> gpurun_out/sweep.log
+timeout -k 10 400 python -u tools/exactness_sweep.py file:gpurun_out/warped.scene 0 11 4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
+tail -48 gpurun_out/sweep.log
