@@ -32,7 +32,7 @@ struct alignas(128) WideNode {
     float mnx[4], mny[4], mnz[4];
     float mxx[4], mxy[4], mxz[4];
     uint32_t ref[4];
-    uint32_t pad[4];
+    float ovh[4];  // per slot: how far a hit in that subtree can lie outside its object's box (0 in most scenes)
 };
 static_assert(sizeof(WideNode) == 128, "wide node must be one 128-byte line");
 constexpr uint32_t WIDE_EMPTY = 0xFFFFFFFFu;

@@ -52,6 +52,7 @@ struct Emit {
 struct EmitWide {
     const BuiltBvh &bvh;
     FlatScene &out;
+    const std::vector<float> &node_ovh;  // per reference node: largest hit overhang in its subtree
 
     static float sa(const BuildNode &n) {
         float dx = n.mx[0] - n.mn[0], dy = n.mx[1] - n.mn[1], dz = n.mx[2] - n.mn[2];
@@ -116,6 +117,7 @@ struct EmitWide {
                 w.mxx[k] = c.mx[0];
                 w.mxy[k] = c.mx[1];
                 w.mxz[k] = c.mx[2];
+                w.ovh[k] = node_ovh[slots[k]];
                 if (c.left < 0) {
                     w.ref[k] = leaf_ref(c);
                 } else {
@@ -206,14 +208,18 @@ int emit_material(const rtx_scene_desc &d, int node, int depth, std::vector<MatI
 // Returns the largest such excess over the objects, in world units (0 for triangles, planar
 // quads, spheres under rotation + uniform scale: every scene of scene.rs except Suzanne's
 // slightly non-planar quads); infinity when a transform is not affine.
-float hit_overhang(const rtx_scene_desc &d) {
+float hit_overhang(const rtx_scene_desc &d, std::vector<float> &per_object) {
     double worst = 0.0;
+    per_object.assign(d.n_objects, 0.0f);
     for (uint32_t o = 0; o < d.n_objects; o++) {
         const int type = d.obj_type[o];
         if (type == RTX_OBJ_TRIANGLE) continue;
         const float *v = d.obj_verts + (size_t)o * 12;
         const float *M = d.xforms + (size_t)d.obj_xform[o] * 32;  // column-major object_to_world
-        if (M[3] != 0.0f || M[7] != 0.0f || M[11] != 0.0f || M[15] != 1.0f) return INFINITY;
+        if (M[3] != 0.0f || M[7] != 0.0f || M[11] != 0.0f || M[15] != 1.0f) {
+            per_object.assign(d.n_objects, INFINITY);
+            return INFINITY;
+        }
         auto world = [&](const double p[3], double w[3]) {
             for (int k = 0; k < 3; k++) w[k] = (double)M[k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
         };
@@ -252,6 +258,7 @@ float hit_overhang(const rtx_scene_desc &d) {
             for (int k = 0; k < 3; k++) size = std::max(size, std::max(std::fabs((double)mn[k]), std::fabs((double)mx[k])));
             if (excess < 4e-7 * size) excess = 0.0;  // a planar quad: f32 rounding of the vertices only
         }
+        per_object[o] = !(excess == excess) ? INFINITY : (excess == 0.0 ? 0.0f : (float)(excess * 1.0001 + 1e-7));
         if (!(excess <= worst)) worst = excess;  // NaN propagates to "no pruning"
     }
     if (!(worst == worst)) return INFINITY;
@@ -388,7 +395,8 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         p.meta = (uint32_t)type | ((uint32_t)xf << 2) | (xf_identity[xf] ? 0x8000u : 0u) | ((uint32_t)mat << 16);
         if (mat_bounce[mat] > out.max_bounce) out.max_bounce = mat_bounce[mat];
     }
-    out.overhang = hit_overhang(d);
+    std::vector<float> obj_ovh;
+    out.overhang = hit_overhang(d, obj_ovh);
     // tree
     if (!bvh.nodes.empty()) {
         Emit e{bvh, out};
@@ -399,7 +407,20 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         if (bvh.nodes[0].left < 0) {
             out.wide_root_ref = out.root_ref;
         } else {
-            EmitWide w{bvh, out};
+            // children are numbered after their parent (bvh_build.cpp), so one descending pass
+            // folds the per-object overhangs up the tree
+            std::vector<float> node_ovh(bvh.nodes.size(), 0.0f);
+            if (out.overhang != 0.0f)
+                for (size_t i = bvh.nodes.size(); i-- > 0;) {
+                    const BuildNode &bn = bvh.nodes[i];
+                    float m = 0.0f;
+                    if (bn.left < 0)
+                        for (uint32_t k = bn.first; k < bn.first + bn.count; k++) m = std::max(m, obj_ovh[bvh.leaf_order[k]]);
+                    else
+                        m = std::max(node_ovh[bn.left], node_ovh[bn.right]);
+                    node_ovh[i] = m;
+                }
+            EmitWide w{bvh, out, node_ovh};
             out.wnodes.reserve(bvh.nodes.size() / 4 + 1);
             w.run(0);
             out.wide_root_ref = 0;

@@ -191,14 +191,8 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     // few bits; |d| ~ 1e20: it overflows): such a ray prunes nothing -- an infinite slack
     // turns every pruning comparison off -- and visits what the reference visits.
     if (!(fabsf(dot(d, d) - 1.0f) <= 4e-6f)) r.slack0 = INFINITY;
-    // A hit can lie up to sc.overhang outside its object's box in space (non-planar quads,
-    // sheared spheres: flatten.cpp, hit_overhang), which is overhang * |1/d_i| in t on the
-    // axis that decides the box's entry or exit; the ill-conditioned axes are not looked at.
-    if (sc.overhang != 0.0f) {  // scene constant: uniform branch, skipped by most scenes
-        float g = fmaxf(fmaxf(r.ill_x() ? 0.0f : fabsf(r.inv.x), r.ill_y() ? 0.0f : fabsf(r.inv.y)),
-                        r.ill_z() ? 0.0f : fabsf(r.inv.z));
-        r.slack0 += sc.overhang * g;
-    }
+    // (Hits that lie outside their object's box -- non-planar quads, sheared spheres -- are
+    // allowed for per node slot, see node_step.)
     set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
 }
 
@@ -433,7 +427,7 @@ struct Trav {
     uint32_t nodes, prims;  // visit counters, accumulated over the lane's rays (COUNT)
 };
 
-template <bool REF>
+template <bool REF, bool OVH>
 __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack &st) {
     s.prim = NO_PRIM;
     s.t = INFINITY;
@@ -445,13 +439,14 @@ __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack
     uint32_t root = REF ? sc.root_ref : sc.wroot_ref;
     if (root == NO_PRIM) return;
     float te;
+    // (no pruning of the root box in scenes whose hits can lie outside their boxes)
     if (box_test(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], s.r,
-                 s.limit_plus, true, !REF, te))
+                 s.limit_plus, true, !REF && !OVH, te))
         s.cur = root;
 }
 
 // Advances a lane that holds an internal node by one node.
-template <bool COUNT, bool REF>
+template <bool COUNT, bool REF, bool OVH>
 __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st, LdsNodePtr lds_top) {
     uint32_t cur = s.cur;
     if (COUNT) s.nodes++;
@@ -518,6 +513,24 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
                     if (k == 3u) { k3 = h; t3 = a; x3 = b; }
                 }
             }
+        }
+        // A hit can lie up to ovh[k] outside its object's box in space (non-planar quads, sheared
+        // spheres: flatten.cpp, hit_overhang; folded up the tree per slot), which is
+        // ovh * |1/d_i| in t on the axis that decides the box's entry or exit (the
+        // ill-conditioned axes are not looked at).  OVH: only the kernels launched for scenes
+        // with an overhang carry this code; the node's line is in the L1 by now.
+        if constexpr (OVH) {
+            const float4 ov = reinterpret_cast<const float4 *>(sc.wnodes + cur)[7];
+            const float g = fmaxf(fmaxf(s.r.ill_x() ? 0.0f : fabsf(s.r.inv.x), s.r.ill_y() ? 0.0f : fabsf(s.r.inv.y)),
+                                  s.r.ill_z() ? 0.0f : fabsf(s.r.inv.z));
+            t0 -= ov.x * g;
+            x0 += ov.x * g;
+            t1 -= ov.y * g;
+            x1 += ov.y * g;
+            t2 -= ov.z * g;
+            x2 += ov.z * g;
+            t3 -= ov.w * g;
+            x3 += ov.w * g;
         }
         // pruning: box behind the origin or beyond the best hit
         const float back = s.r.ill_any() ? -INFINITY : -s.r.slack0, lim = s.limit_plus;
@@ -627,7 +640,7 @@ struct Util {
     }
 };
 
-template <int MODE, bool COUNT, bool REF>
+template <int MODE, bool COUNT, bool REF, bool OVH>
 __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist, LdsNodePtr lds_top,
                                           Util &u) {
     bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
@@ -647,7 +660,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
         u.node_steps++;
         u.node_lanes += nn;
 #endif
-        if (at_node) node_step<COUNT, REF>(sc, s, st, lds_top);
+        if (at_node) node_step<COUNT, REF, OVH>(sc, s, st, lds_top);
     }
 }
 
@@ -786,8 +799,8 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
 }
 
 // ---------------------------------------------------------------- trace_closest
-template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+template <bool COUNT, bool REF, bool OVH>
+__device__ __forceinline__ void trace_closest_body(const DeviceScene &sc, const Frame &fr, uint32_t level) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
@@ -827,7 +840,7 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(
                 float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
                 if (__float_as_uint(d4.w) != INVALID_PRIM) {
                     init_ray(s.r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
-                    trav_begin<REF>(sc, s, st);
+                    trav_begin<REF, OVH>(sc, s, st);
                     if (s.cur == TRAV_DONE) {  // misses the root box
                         fr.ray_o[node].w = 0.0f;
                         fr.ray_d[node].w = __uint_as_float(NO_PRIM);
@@ -841,7 +854,7 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(
         do {
             bool active = s.cur != TRAV_DONE;
             uint32_t before = s.nodes + s.prims;
-            wave_step<0, COUNT, REF>(sc, s, st, 0.0f, lds_top, util);
+            wave_step<0, COUNT, REF, OVH>(sc, s, st, 0.0f, lds_top, util);
             if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 fr.ray_o[node].w = s.any ? s.t : 0.0f;
@@ -858,6 +871,17 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(
         add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
         atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
     }
+}
+
+template <bool COUNT, bool REF>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    trace_closest_body<COUNT, REF, false>(sc, fr, level);
+}
+// The production traversal for scenes whose hits can lie outside their objects' boxes
+// (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
+template <bool COUNT>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_ovh_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    trace_closest_body<COUNT, false, true>(sc, fr, level);
 }
 
 // ---------------------------------------------------------------- object.rs helpers for shading
@@ -1060,8 +1084,8 @@ __global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Fr
 }
 
 // ---------------------------------------------------------------- trace_shadow
-template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+template <bool COUNT, bool REF, bool OVH>
+__device__ __forceinline__ void trace_shadow_body(const DeviceScene &sc, const Frame &fr, uint32_t level) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
@@ -1132,7 +1156,7 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(D
                     dist = magnitude(lpos - p);
                     init_ray(s.r, sc, lpos, rd);
                 }
-                trav_begin<REF>(sc, s, st);
+                trav_begin<REF, OVH>(sc, s, st);
                 // a ray that misses the root box hits nothing: directional light reaches,
                 // point / cone light does not (light.rs:93-96)
                 if (s.cur == TRAV_DONE && directional) atomicOr(&fr.link[node].x, 1u << l);
@@ -1143,7 +1167,7 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(D
         do {
             bool active = s.cur != TRAV_DONE;
             uint32_t before = s.nodes + s.prims;
-            wave_step<1, COUNT, REF>(sc, s, st, dist, lds_top, util);
+            wave_step<1, COUNT, REF, OVH>(sc, s, st, dist, lds_top, util);
             if (COUNT) ray_steps += s.nodes + s.prims - before;
             if (active && s.cur == TRAV_DONE) {
                 bool reaches = (light & 0x100u) ? !s.any : (s.any && !s.occluded);
@@ -1160,6 +1184,15 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(D
         add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
         atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
     }
+}
+
+template <bool COUNT, bool REF>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    trace_shadow_body<COUNT, REF, false>(sc, fr, level);
+}
+template <bool COUNT>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_ovh_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    trace_shadow_body<COUNT, false, true>(sc, fr, level);
 }
 
 // ---------------------------------------------------------------- resolve
@@ -1369,6 +1402,9 @@ void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level
     if (lc.reference_traversal) {
         if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_closest_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
+    } else if (sc.overhang != 0.0f) {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_ovh_kernel<true>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_closest_ovh_kernel<false>), g, b, 0, lc.stream, sc, fr, level);
     } else {
         if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_closest_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
@@ -1379,6 +1415,9 @@ void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level,
     if (lc.reference_traversal) {
         if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_shadow_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
+    } else if (sc.overhang != 0.0f) {
+        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_ovh_kernel<true>), g, b, 0, lc.stream, sc, fr, level);
+        else hipLaunchKernelGGL((trace_shadow_ovh_kernel<false>), g, b, 0, lc.stream, sc, fr, level);
     } else {
         if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
         else hipLaunchKernelGGL((trace_shadow_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
