@@ -10,4 +10,6 @@ done
 # objects that can be hit outside their boxes (non-planar quads, sheared spheres), through a scene file
 python tools/make_warped_scene.py gpurun_out/warped.scene 40 9 >> gpurun_out/sweep.log
 timeout -k 10 400 python -u tools/exactness_sweep.py file:gpurun_out/warped.scene 0 11 4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
-tail -48 gpurun_out/sweep.log
+# lights placed where shadow queries degenerate (axis-parallel directional lights, a point light on a vertex)
+timeout -k 10 400 python -u tools/exactness_sweep.py file:assets/scenes/adversarial_lights.scene 0 51 4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
+tail -56 gpurun_out/sweep.log

@@ -475,3 +475,19 @@ def test_scene_file_renders_like_builtin(rt, gpu):
         out.append((obj, t, img))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
     assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_adversarial_lights_scene_matches_oracle(rt, orc, gpu):
+    """assets/scenes/adversarial_lights.scene: a directional light exactly along -y and one along
+    +x (shadow rays with two zero direction components), a point light ON a mesh vertex, a cone
+    light lying in the floor plane; mirror + glass + Phong mix on two Suzannes and a sphere."""
+    s, o = _pair(rt, orc, gpu, "file:" + os.path.join(rt.MEDIA_DIR, "scenes", "adversarial_lights.scene"), 80, 0)
+    obj_o, t_o = o.trace_primary()
+    obj_g, t_g = gpu.trace_primary()
+    assert np.array_equal(obj_g, obj_o) and np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    for spp in (1, 3):
+        img_o, st_o = o.render(spp=spp, bounces=4, seed=2)
+        img_g, st_g = gpu.render(spp=spp, bounces=4, seed=2)
+        ok, frac, worst = _image_close(img_g, img_o)
+        assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
+        assert abs(int(st_g.shadow_rays) - int(st_o.shadow_rays)) <= max(4, st_o.shadow_rays // 10000)
