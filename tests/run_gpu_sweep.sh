@@ -13,3 +13,10 @@ timeout -k 10 400 python -u tools/exactness_sweep.py file:gpurun_out/warped.scen
 # lights placed where shadow queries degenerate (axis-parallel directional lights, a point light on a vertex)
 timeout -k 10 400 python -u tools/exactness_sweep.py file:assets/scenes/adversarial_lights.scene 0 51 4 >> gpurun_out/sweep.log 2>&1 || { tail -20 gpurun_out/sweep.log; exit 1; }
 tail -56 gpurun_out/sweep.log
+# the same families against the CPU oracle (moderate sizes: the oracle visits both children of every node)
+: > gpurun_out/oracle_sweep.log
+for spec in "basic_suzanne 0 61 4" "scan 200000 62 3" "random_spheres 1000 63 3" "file:gpurun_out/warped.scene 0 64 3" "file:assets/scenes/adversarial_lights.scene 0 65 3" "soup 200000 66 2"; do
+  set -- $spec
+  timeout -k 10 280 python -u tests/oracle_sweep.py $1 $2 $3 $4 >> gpurun_out/oracle_sweep.log 2>&1 || { tail -20 gpurun_out/oracle_sweep.log; exit 1; }
+done
+grep -E "TOTAL|param" gpurun_out/oracle_sweep.log

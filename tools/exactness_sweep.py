@@ -16,57 +16,48 @@ sys.path.insert(0, ROOT)
 import numpy as np
 rt = importlib.import_module("rust-raytracer_amd")
 
-scene, param, seed, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-n = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
-gpu = rt.Context(0)
-s = rt.HostScene(scene, 64, param)
-gpu.upload(s)
-# shading check: World::trace_ray colours (bounces and any-hit shadow queries included) from a
-# second context that runs the verbatim traversal everywhere; same shading code, so bit-equal
-SHADE = os.environ.get("SWEEP_SHADE", "1") != "0"
-if SHADE:
-    os.environ["RTX_REFERENCE_TRAVERSAL"] = "1"
-    gref = rt.Context(0)
-    del os.environ["RTX_REFERENCE_TRAVERSAL"]
-    gref.upload(s)
-d = s.desc.contents
-N = d.n_objects
-typ = np.ctypeslib.as_array(d.obj_type, (N,))
-verts = np.ctypeslib.as_array(d.obj_verts, (N, 12)).astype(np.float64)
-xf = np.ctypeslib.as_array(d.obj_xform, (N,))
-mats = np.ctypeslib.as_array(d.xforms, (d.n_xforms, 32)).astype(np.float64)[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
+def geometry(s):
+    """World-space vertex data of a HostScene for the ray families."""
+    d = s.desc.contents
+    N = d.n_objects
+    typ = np.ctypeslib.as_array(d.obj_type, (N,))
+    verts = np.ctypeslib.as_array(d.obj_verts, (N, 12)).astype(np.float64)
+    xf = np.ctypeslib.as_array(d.obj_xform, (N,))
+    mats = np.ctypeslib.as_array(d.xforms, (d.n_xforms, 32)).astype(np.float64)[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
 
 
-def to_world(p, idx):
-    m = mats[xf[idx]]
-    w = np.einsum("nij,nj->ni", m[:, :3, :3], p) + m[:, :3, 3]
-    return w
+    def to_world(p, idx):
+        m = mats[xf[idx]]
+        w = np.einsum("nij,nj->ni", m[:, :3, :3], p) + m[:, :3, 3]
+        return w
 
 
-poly = np.nonzero(typ != 0)[0]
-sph = np.nonzero(typ == 0)[0]
-tri_a = to_world(verts[poly, 0:3], poly)
-tri_b = to_world(verts[poly, 3:6], poly)
-tri_c = to_world(verts[poly, 6:9], poly)
-vlist = [tri_a, tri_b, tri_c]
-quads = poly[typ[poly] == 2]
-if len(quads):
-    vlist.append(to_world(verts[quads, 9:12], quads))
-if len(sph):
-    c, r = verts[sph, 0:3], verts[sph, 3:4]
-    for k in range(3):
-        for sg in (-1.0, 1.0):
-            e = np.zeros(3)
-            e[k] = sg
-            vlist.append(to_world(c + r * e, sph))
-vw = np.concatenate(vlist)
-lo, hi = vw.min(0), vw.max(0)
-ext = float((hi - lo).max())
-print(f"{scene} param {param}: {N} objects, {len(vw)} vertices, extent {ext:.3g}", flush=True)
-rng = np.random.default_rng(seed)
-bad = 0
-total = 0
-for rep in range(reps):
+    poly = np.nonzero(typ != 0)[0]
+    sph = np.nonzero(typ == 0)[0]
+    tri_a = to_world(verts[poly, 0:3], poly)
+    tri_b = to_world(verts[poly, 3:6], poly)
+    tri_c = to_world(verts[poly, 6:9], poly)
+    vlist = [tri_a, tri_b, tri_c]
+    quads = poly[typ[poly] == 2]
+    if len(quads):
+        vlist.append(to_world(verts[quads, 9:12], quads))
+    if len(sph):
+        c, r = verts[sph, 0:3], verts[sph, 3:4]
+        for k in range(3):
+            for sg in (-1.0, 1.0):
+                e = np.zeros(3)
+                e[k] = sg
+                vlist.append(to_world(c + r * e, sph))
+    vw = np.concatenate(vlist)
+    lo, hi = vw.min(0), vw.max(0)
+    ext = float((hi - lo).max())
+    return dict(N=N, vw=vw, lo=lo, hi=hi, ext=ext, poly=poly, tri_a=tri_a, tri_b=tri_b, tri_c=tri_c)
+
+
+def make_rays(rng, geo, n):
+    """One repetition: n/8 rays of each family; returns (rays float32 [8m, 6], family ids, m)."""
+    vw, lo, hi, ext, poly = geo['vw'], geo['lo'], geo['hi'], geo['ext'], geo['poly']
+    tri_a, tri_b, tri_c = geo['tri_a'], geo['tri_b'], geo['tri_c']
     m = n // 8
     fam = np.repeat(np.arange(8), m)
     org = np.zeros((8 * m, 3))
@@ -137,31 +128,59 @@ for rep in range(reps):
     o7 = rng.uniform(lo - ext, hi + ext, (m, 3))
     org[7 * m:], dirv[7 * m:] = o7, (t7 - o7) * 10.0 ** rng.uniform(-30, 30, (m, 1))
     rays = np.concatenate([org, dirv], axis=1).astype(np.float32)
-    obj_g, t_g = gpu.trace_rays(rays)
-    obj_r, t_r = gpu.trace_rays(rays, flags=rt.FLAG_REFERENCE_TRAVERSAL)
-    diff = (obj_g != obj_r) | (t_g.view(np.uint32) != t_r.view(np.uint32))
+    return rays, fam, m
+
+
+def main():
+    scene, param, seed, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    n = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
+    gpu = rt.Context(0)
+    s = rt.HostScene(scene, 64, param)
+    gpu.upload(s)
+    # shading check: World::trace_ray colours (bounces and any-hit shadow queries included) from a
+    # second context that runs the verbatim traversal everywhere; same shading code, so bit-equal
+    SHADE = os.environ.get("SWEEP_SHADE", "1") != "0"
     if SHADE:
-        k = len(rays) // 4            # a quarter of every family (the verbatim traversal shades slowly)
-        sub = rays.reshape(8, m, 6)[:, : m // 4].reshape(-1, 6)
-        c_p = gpu.shade_rays(sub, depth=3)
-        c_r = gref.shade_rays(sub, depth=3)
-        cd = (c_p.view(np.uint32) != c_r.view(np.uint32)).any(axis=1)
-        sdiff = np.zeros(len(rays), bool)
-        sdiff.reshape(8, m)[:, : m // 4] = cd.reshape(8, m // 4)
-        diff = diff | sdiff
-        shade_note = f" shaded {len(sub)} colour mismatches {int(cd.sum())}"
-    else:
-        shade_note = ""
-    bad += int(diff.sum())
-    total += len(rays)
-    hits = obj_r != 0xFFFFFFFF
-    per = " ".join(f"{k}:{int(diff[fam == k].sum())}/{hits[fam == k].mean():.2f}" for k in range(8))
-    print(f"rep {rep}: {len(rays)} rays,{shade_note} mismatches {int(diff.sum())}   family:mismatches/hit-fraction {per}", flush=True)
-    if diff.any():
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"sweep_mismatch_{scene.replace('/', '_').replace(':', '_')}.txt"), "a") as f:
-            for i in np.nonzero(diff)[0][:32]:
-                f.write(f"{int(fam[i])} " + " ".join(repr(float(x)) for x in rays[i]) +
-                        f"  prod {int(obj_g[i])} {float(t_g[i])!r} ref {int(obj_r[i])} {float(t_r[i])!r}\n")
-print(f"TOTAL {total} rays, MISMATCHES {bad}")
-sys.exit(1 if bad else 0)
+        os.environ["RTX_REFERENCE_TRAVERSAL"] = "1"
+        gref = rt.Context(0)
+        del os.environ["RTX_REFERENCE_TRAVERSAL"]
+        gref.upload(s)
+    geo = geometry(s)
+    print(f"{scene} param {param}: {geo['N']} objects, {len(geo['vw'])} vertices, extent {geo['ext']:.3g}", flush=True)
+    rng = np.random.default_rng(seed)
+    bad = 0
+    total = 0
+    for rep in range(reps):
+        rays, fam, m = make_rays(rng, geo, n)
+        obj_g, t_g = gpu.trace_rays(rays)
+        obj_r, t_r = gpu.trace_rays(rays, flags=rt.FLAG_REFERENCE_TRAVERSAL)
+        diff = (obj_g != obj_r) | (t_g.view(np.uint32) != t_r.view(np.uint32))
+        if SHADE:
+            k = len(rays) // 4            # a quarter of every family (the verbatim traversal shades slowly)
+            sub = rays.reshape(8, m, 6)[:, : m // 4].reshape(-1, 6)
+            c_p = gpu.shade_rays(sub, depth=3)
+            c_r = gref.shade_rays(sub, depth=3)
+            cd = (c_p.view(np.uint32) != c_r.view(np.uint32)).any(axis=1)
+            sdiff = np.zeros(len(rays), bool)
+            sdiff.reshape(8, m)[:, : m // 4] = cd.reshape(8, m // 4)
+            diff = diff | sdiff
+            shade_note = f" shaded {len(sub)} colour mismatches {int(cd.sum())}"
+        else:
+            shade_note = ""
+        bad += int(diff.sum())
+        total += len(rays)
+        hits = obj_r != 0xFFFFFFFF
+        per = " ".join(f"{k}:{int(diff[fam == k].sum())}/{hits[fam == k].mean():.2f}" for k in range(8))
+        print(f"rep {rep}: {len(rays)} rays,{shade_note} mismatches {int(diff.sum())}   family:mismatches/hit-fraction {per}", flush=True)
+        if diff.any():
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"sweep_mismatch_{scene.replace('/', '_').replace(':', '_')}.txt"), "a") as f:
+                for i in np.nonzero(diff)[0][:32]:
+                    f.write(f"{int(fam[i])} " + " ".join(repr(float(x)) for x in rays[i]) +
+                            f"  prod {int(obj_g[i])} {float(t_g[i])!r} ref {int(obj_r[i])} {float(t_r[i])!r}\n")
+    print(f"TOTAL {total} rays, MISMATCHES {bad}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
