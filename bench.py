@@ -88,7 +88,13 @@ def main():
     tiles = torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device)
     frame = [None]
 
+    # the library renders on its own stream; the gather runs on torch's: order the next frame's
+    # writes to `tiles` after the previous frame's all-gather has read them (device-side wait)
+    lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device) if world > 1 else None
+
     def step(flags=0):
+        if lib_stream is not None:
+            lib_stream.wait_stream(torch.cuda.current_stream(device))
         st = ctx.render_device(tiles.data_ptr(), args.spp, args.bounces, seed=1, part=part, flags=flags)
         if world > 1:  # the frame's one exchange step: RGB8 tiles over RCCL, then de-interleave
             frame[0] = tl.gather_image(tiles, args.width, args.width, args.tile, rank, world, dist)

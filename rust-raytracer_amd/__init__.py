@@ -354,6 +354,11 @@ class Context:
                                             C.byref(st) if stats else None))
         return st
 
+    @property
+    def stream(self):
+        """The hipStream_t (as an integer) that this context's renders are ordered on (rtx_stream)."""
+        return int(lib().rtx_stream(self._h) or 0)
+
     def synchronize(self):
         self._check(lib().rtx_synchronize(self._h))
 
