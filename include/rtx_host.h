@@ -61,6 +61,14 @@ int rtx_render_builtin_to_png(const char *scene, uint32_t width, const char *med
 int rtx_host_bvh_digest(const rtx_scene_desc *desc, int threads, uint32_t *leaf_order, uint32_t *preorder_sizes,
                         uint32_t *depth, float *total_sa, uint32_t *n_internal);
 
+/* How far a hit can lie outside the box the reference bounds its object with, in world units
+ * (largest value over the scene; no counterpart in the reference, which never asks): 0 for
+ * triangles, planar quads and spheres under rotation + uniform scale, positive for non-planar
+ * quads (object.rs:167-189 vs 284-299) and sheared spheres (utils.rs:33-44), infinity for a
+ * transform that is not affine, negative rtx_status (as a float) for a bad descriptor.  Scenes
+ * with a non-zero value are traced by the `_ovh` kernels (exactness). */
+float rtx_scene_hit_overhang(const rtx_scene_desc *desc);
+
 #ifdef __cplusplus
 }
 #endif

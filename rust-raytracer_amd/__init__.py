@@ -119,6 +119,8 @@ def lib():
     L.rtx_render_builtin_to_png.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                             C.c_char_p, C.c_uint32, C.c_int]
     L.rtx_host_bvh_digest.argtypes = [C.POINTER(SceneDesc), C.c_int, _u32p, _u32p, _u32p, _f32p, _u32p]
+    L.rtx_scene_hit_overhang.argtypes = [C.POINTER(SceneDesc)]
+    L.rtx_scene_hit_overhang.restype = C.c_float
     _lib = L
     return L
 
@@ -286,6 +288,11 @@ class ArrayScene:
         self._desc = d
         self.desc = C.pointer(d)
         self.width, self.height, self.n_objects = width, height, n
+
+
+def hit_overhang(scene):
+    """rtx_scene_hit_overhang: how far a hit can lie outside its object's reference box (0 for most scenes)."""
+    return float(lib().rtx_scene_hit_overhang(scene.desc))
 
 
 def host_bvh_digest(scene, threads=8):

@@ -31,6 +31,10 @@ struct FlatScene {
     float overhang = 0.0f;              // how far a hit point can lie outside its object's reference box (flatten.cpp)
 };
 
+// Largest distance by which a hit can lie outside its object's reference box; per_object gets
+// every object's own value.  Expects validated object indices.
+float hit_overhang(const rtx_scene_desc &d, std::vector<float> &per_object);
+
 int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err);
 
 }  // namespace rtx

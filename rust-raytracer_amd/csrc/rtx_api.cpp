@@ -864,4 +864,17 @@ int rtx_host_bvh_digest(const rtx_scene_desc *d, int threads, uint32_t *leaf_ord
     return (int)fs.preorder_sizes.size();
 }
 
+float rtx_scene_hit_overhang(const rtx_scene_desc *d) {
+    if (!d) return (float)RTX_ERR_INVALID;
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        int type = d->obj_type[i], xf = d->obj_xform[i];
+        if (type < 0 || type > 2 || xf < 0 || (uint32_t)xf >= d->n_xforms) {
+            g_init_error = "object with bad type / transform index";
+            return (float)RTX_ERR_INVALID;
+        }
+    }
+    std::vector<float> per_object;
+    return hit_overhang(*d, per_object);
+}
+
 }  // extern "C"

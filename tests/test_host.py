@@ -111,6 +111,33 @@ def test_bad_object_indices_are_rejected(rt):
         assert e.value.status == rt.RTX_ERR_INVALID, field
 
 
+def test_hit_overhang(rt, tmp_path):
+    """Only non-planar quads and sheared spheres can be hit outside their boxes.  The headline
+    scene must report exactly 0: a non-zero value selects the kernels with the per-slot allowance."""
+    for name, param in (("basic", 0), ("random_spheres", 300), ("scan", 30000), ("scan_glass", 5000), ("soup", 20000)):
+        assert rt.hit_overhang(rt.HostScene(name, 16, param)) == 0.0, name
+    assert rt.hit_overhang(rt.HostScene("scan", 16, 0)) == 0.0
+    assert 0.085 < rt.hit_overhang(rt.HostScene("suzanne", 16)) < 0.095          # some of its quads are far from planar
+    flat = ("quad", (0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1))
+    assert rt.hit_overhang(rt.ArrayScene([flat])) == 0.0
+    # c lifted by 1 above the plane of a, b, d and hanging outside the vertices' box in x: the hit
+    # region reaches its projection (1.5, 0, 1)
+    warped = ("quad", (0, 0, 0), (1, 0, 0), (1.5, 1, 1), (0, 0, 1))
+    assert abs(rt.hit_overhang(rt.ArrayScene([warped])) - 0.0) < 1e-6             # projection (1.5,0,1) is inside x <= 1.5
+    warped = ("quad", (0, 0, 0), (1, 0, 0), (1, 1, 1), (0, 0.5, 1))               # tilted plane: projection of c leaves the box
+    assert rt.hit_overhang(rt.ArrayScene([warped])) > 0.05
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    rot = np.array([[c, -s_, 0, 0], [s_, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    shear = rot @ np.diag([3.0, 0.5, 1.0, 1.0])
+    sph = [("sphere", (0, 0, 0), 1.0, 0, 1)]
+    ov = rt.hit_overhang(rt.ArrayScene(sph, xforms=[(np.eye(4), np.eye(4)), (shear, np.linalg.inv(shear))]))
+    rows, cols = np.linalg.norm(shear[:3, :3], axis=1), np.linalg.norm(shear[:3, :3], axis=0)
+    assert abs(ov - max(0.0, (rows - cols).max())) < 1e-3 and ov > 0.1
+    assert rt.hit_overhang(rt.ArrayScene(sph, xforms=[(np.eye(4), np.eye(4)), (rot, rot.T)])) == 0.0
+    persp = np.eye(4); persp[3, 2] = 0.1
+    assert rt.hit_overhang(rt.ArrayScene(sph, xforms=[(np.eye(4), np.eye(4)), (persp, np.linalg.inv(persp))])) == float("inf")
+
+
 def test_empty_and_tiny_scenes(rt, orc):
     leaf, pre, depth, sa, n_int = rt.host_bvh_digest(rt.ArrayScene([]))
     assert len(leaf) == 0 and len(pre) == 0
