@@ -131,6 +131,10 @@ const char *rtx_last_error(rtx_ctx *ctx); /* ctx may be NULL: last rtx_init erro
  * reference's SAH tree topology on the host, flattens it into 64-byte node / primitive
  * records and uploads everything to HBM once. */
 int rtx_upload_scene(rtx_ctx *ctx, const rtx_scene_desc *desc);
+/* Host threads the next rtx_upload_scene builds the BVH with: render's `num_threads`
+ * (world.rs:28, -t/--threads of main.rs:40-47); 0 = min(16, hardware threads).  The tree is the
+ * same for every thread count. */
+int rtx_set_build_threads(rtx_ctx *ctx, int threads);
 int rtx_bvh_info_get(rtx_ctx *ctx, rtx_bvh_info *out);
 /* Leaf-order permutation of object indices and preorder node sizes of the built tree
  * (parity check of the topology against the reference builder). Returns node count. */

@@ -49,7 +49,8 @@ int rtx_png_write_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *
 void rtx_host_free(void *p);
 
 /* world::render (world.rs:17-29) on a built-in scene: upload, trace on `device`, save PNG.
- * num_threads is accepted for signature compatibility and used only for the BVH build. */
+ * num_threads drives the host BVH build (rtx_set_build_threads; 0 = default), the trace runs on the GPU.
+ * The PNG has the camera's size: width x width for the built-in scenes, the `size W H` of a scene file. */
 int rtx_render_builtin_to_png(const char *scene, uint32_t width, const char *media_dir, uint64_t param,
                               uint32_t samples_per_pixel, uint32_t max_ray_bounces, const char *path,
                               uint32_t num_threads, int device);

@@ -97,6 +97,7 @@ def lib():
                              C.POINTER(Stats)]
     L.rtx_render_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32, vp,
                                     C.POINTER(Stats)]
+    L.rtx_set_build_threads.argtypes = [vp, C.c_int]
     L.rtx_partition_pixels.argtypes = [vp, C.POINTER(Partition)]
     L.rtx_partition_pixels.restype = C.c_uint64
     L.rtx_stream.argtypes = [vp]
@@ -361,6 +362,9 @@ class Context:
                                             C.byref(st) if stats else None))
         return st
 
+    def set_build_threads(self, n):
+        self._check(lib().rtx_set_build_threads(self._h, n))
+
     @property
     def stream(self):
         """The hipStream_t (as an integer) that this context's renders are ordered on (rtx_stream)."""
@@ -399,6 +403,59 @@ class Context:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+_hip = None
+
+
+def _hiprt():
+    """The HIP runtime that librtx_hip.so itself is linked against (same soname: the copy already
+    mapped), for the few tests and bench paths that need a caller-owned device buffer."""
+    global _hip
+    if _hip is None:
+        lib()
+        h = C.CDLL("libamdhip64.so.7")
+        h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        h.hipFree.argtypes = [C.c_void_p]
+        h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        h.hipDeviceSynchronize.argtypes = []
+        _hip = h
+    return _hip
+
+
+class DeviceBuffer:
+    """`nbytes` of device memory on the current HIP device (hipMalloc), filled with `fill`."""
+
+    def __init__(self, nbytes, fill=0):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        rc = _hiprt().hipMalloc(C.byref(p), max(self.nbytes, 256))
+        if rc != 0 or not p.value:
+            raise RtxError(RTX_ERR_HIP, f"hipMalloc({nbytes}) failed with {rc}")
+        self.ptr = p.value
+        _hiprt().hipMemset(C.c_void_p(self.ptr), fill, max(self.nbytes, 256))
+        _hiprt().hipDeviceSynchronize()
+
+    def to_host(self):
+        """Synchronous copy to a numpy uint8 array (after all work of the device has finished)."""
+        out = np.empty(self.nbytes, np.uint8)
+        _hiprt().hipDeviceSynchronize()
+        rc = _hiprt().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.nbytes, 2)  # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise RtxError(RTX_ERR_HIP, f"hipMemcpy failed with {rc}")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _hiprt().hipFree(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass
 

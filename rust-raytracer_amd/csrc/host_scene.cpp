@@ -687,7 +687,6 @@ namespace rtx {
 int render(const Camera &camera, const std::vector<Object> &objects, const std::vector<Light> &lights, Color background_color,
            uint16_t samples_per_pixel, uint16_t max_ray_bounces, const std::string &path, size_t num_threads, int device,
            std::string *error) {
-    (void)num_threads;
     SceneArrays s;
     s.set_camera(camera);
     s.set_background(background_color);
@@ -705,6 +704,7 @@ int render(const Camera &camera, const std::vector<Object> &objects, const std::
         if (error) *error = rtx_last_error(nullptr);
         return rc;
     }
+    if (num_threads) (void)rtx_set_build_threads(ctx, (int)num_threads);
     rc = rtx_upload_scene(ctx, &d);
     std::vector<uint8_t> img((size_t)camera.width * camera.height * 3);
     if (rc == RTX_OK) rc = rtx_render(ctx, samples_per_pixel, max_ray_bounces, 0, nullptr, 0, img.data(), nullptr, nullptr);
@@ -769,7 +769,6 @@ void rtx_host_free(void *p) { std::free(p); }
 
 int rtx_render_builtin_to_png(const char *scene, uint32_t width, const char *media_dir, uint64_t param, uint32_t spp,
                               uint32_t bounces, const char *path, uint32_t num_threads, int device) {
-    (void)num_threads;
     if (!path) return RTX_ERR_INVALID;
     rtx_host_scene *hs = rtx_scene_builtin(scene, width, media_dir, param);
     if (!hs) return RTX_ERR_INVALID;
@@ -780,14 +779,17 @@ int rtx_render_builtin_to_png(const char *scene, uint32_t width, const char *med
         rtx_scene_free(hs);
         return rc;
     }
+    if (num_threads) (void)rtx_set_build_threads(ctx, (int)num_threads);
     rc = rtx_upload_scene(ctx, &hs->desc);
-    std::vector<uint8_t> img((size_t)width * width * 3);
+    // a scene file may carry its own `size W H` (scene_file.cpp): the image is the camera's, not width x width
+    const uint32_t img_w = hs->desc.width, img_h = hs->desc.height;
+    std::vector<uint8_t> img((size_t)img_w * img_h * 3);
     if (rc == RTX_OK) rc = rtx_render(ctx, spp, bounces, 0, nullptr, 0, img.data(), nullptr, nullptr);
     if (rc != RTX_OK) g_host_err = rtx_last_error(ctx);
     rtx_destroy(ctx);
     rtx_scene_free(hs);
     if (rc != RTX_OK) return rc;
-    return png_write_rgb8(path, width, width, img.data(), g_host_err) ? RTX_OK : RTX_ERR_IO;
+    return png_write_rgb8(path, img_w, img_h, img.data(), g_host_err) ? RTX_OK : RTX_ERR_IO;
 }
 
 }  // extern "C"

@@ -674,19 +674,24 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #endif
 struct WaveQueue {
     uint32_t *heads;
-    uint32_t count, chunk, psize, dyn0, p0, tried;
+    uint32_t count, chunk, psize, nwaves, p0, tried;
     uint32_t next, end;
     bool exhausted;
     // Sub-queue p covers [p*psize, (p+1)*psize).  Its first waves_per_part*chunk entries
     // are dealt statically (wave j of the sub-queue owns chunk j: no atomic at all for
     // queues that small); the rest is handed out through the sub-queue's head counter.
-    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nwaves, uint32_t wave) {
+    // Statically dealt entries of sub-queue p: one chunk per wave that exists in it (wave j*QPARTS+p
+    // for j*QPARTS+p < nwaves) -- a chunk without an owner would never be traced.
+    __device__ __forceinline__ uint32_t dyn0_of(uint32_t p) const {
+        return p < nwaves ? ((nwaves - p + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS) * chunk : 0u;
+    }
+    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nw, uint32_t wave) {
         heads = h;
         count = n;
+        nwaves = nw;
         uint32_t c = n / (nwaves * 4u);
         chunk = c < 64u ? 64u : (c > 256u ? 256u : c);
         psize = ((n + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS + 63u) & ~63u;
-        dyn0 = ((nwaves + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS) * chunk;
         p0 = wave % (uint32_t)QPARTS;
         tried = 0;
         exhausted = n == 0;
@@ -707,6 +712,7 @@ struct WaveQueue {
             uint32_t p = (p0 + tried) % (uint32_t)QPARTS;
             uint32_t pb = p * psize;
             uint32_t pe = pb + psize < count ? pb + psize : count;
+            const uint32_t dyn0 = dyn0_of(p);
             uint32_t dyn = (pb < count && pe - pb > dyn0) ? pe - pb - dyn0 : 0u;
             uint32_t *hp = heads + p * (uint32_t)QHEAD_STRIDE;
             uint32_t b = dyn;

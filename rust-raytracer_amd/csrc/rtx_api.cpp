@@ -30,7 +30,8 @@ struct Pipe {
     Frame fr{};
     std::vector<void *> allocs;
     uint64_t node_cap = 0, q_cap = 0;
-    uint32_t lights = 0, levels = 0;
+    uint32_t lights = 0, levels = 0, spill_entries = 0;
+    bool side_spills = false;
     hipStream_t main = nullptr;
     std::vector<hipStream_t> sides;   // trace_shadow(k) runs on sides[k % n], beside trace_closest(k+1)
     std::vector<uint32_t *> spill_side;  // traversal-stack overflow of the kernels on each side stream
@@ -62,6 +63,8 @@ struct rtx_ctx {
     std::vector<hipEvent_t> events;
     uint64_t node_budget_bytes = 32ull << 30;
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
+    int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
+    uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
     uint64_t overlap_below = ~0ull;  // renders with fewer primary samples run their kernels concurrently (RTX_CONCURRENT=0: none)
 };
 
@@ -155,8 +158,9 @@ uint64_t geo_last(uint32_t K, uint32_t levels) {
     return std::max<uint64_t>(g, 1);
 }
 
-// Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep.
-int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
+// Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep
+// (`side_spills`: also the stack-spill buffers of the side streams, for the concurrent schedule).
+int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels, bool side_spills = false) {
     uint32_t K = c->max_bounce;
     uint64_t node_cap = n0 * geo_sum(K, levels);
     uint64_t q_cap = n0 * geo_last(K, levels);
@@ -165,17 +169,20 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
         c->err = "batch exceeds 2^32 path nodes";
         return RTX_ERR_CAPACITY;
     }
-    if (pp.fr.ray_o && node_cap <= pp.node_cap && q_cap <= pp.q_cap && nl <= pp.lights && levels <= pp.levels) {
+    if (pp.fr.ray_o && node_cap <= pp.node_cap && q_cap <= pp.q_cap && nl <= pp.lights && levels <= pp.levels &&
+        c->spill_entries <= pp.spill_entries && (!side_spills || pp.side_spills)) {
         pp.fr.node_cap = (uint32_t)pp.node_cap;
         pp.fr.q_cap = (uint32_t)pp.q_cap;
         return RTX_OK;
     }
+    side_spills = side_spills || pp.side_spills;
     HIP_TRY(c, hipStreamSynchronize(pp.main));
     for (auto sd : pp.sides) HIP_TRY(c, hipStreamSynchronize(sd));
     free_all(pp.allocs);
     pp.fr = Frame{};
     pp.spill_side.assign(pp.sides.size(), nullptr);
     pp.node_cap = pp.q_cap = 0;
+    pp.side_spills = false;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
         if (e == hipSuccess) pp.allocs.push_back(*p);
@@ -188,9 +195,13 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&pp.fr.shadow_q, (size_t)levels * nl * q_cap * sizeof(uint32_t)));
     HIP_TRY(c, alloc((void **)&pp.fr.counters, CTR_WORDS * sizeof(uint32_t)));
     HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
-    size_t threads = (size_t)c->persistent_blocks * 256;
-    HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));  // (ref, t)
-    for (auto &sp : pp.spill_side) HIP_TRY(c, alloc((void **)&sp, threads * (MAX_TREE_DEPTH - LDS_STACK) * sizeof(uint32_t) * 2));
+    // stack overflow beyond the LDS entries, sized from the uploaded tree (not MAX_TREE_DEPTH)
+    const size_t spill_bytes = (size_t)c->persistent_blocks * 256 * c->spill_entries * sizeof(uint32_t) * 2;  // (ref, t)
+    HIP_TRY(c, alloc((void **)&pp.fr.spill, spill_bytes));
+    if (side_spills)
+        for (auto &sp : pp.spill_side) HIP_TRY(c, alloc((void **)&sp, spill_bytes));
+    pp.side_spills = side_spills;
+    pp.spill_entries = c->spill_entries;
     pp.node_cap = node_cap;
     pp.q_cap = q_cap;
     pp.lights = nl;
@@ -263,7 +274,7 @@ struct Batch {
 int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0, bool overlap) {
     const size_t ns = pp.sides.size();
     if (ns == 0) overlap = false;
-    while (pp.order.size() < (size_t)levels + ns) {
+    while (overlap && pp.order.size() < (size_t)levels + ns) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pp.order.push_back(e);
@@ -361,7 +372,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
     const size_t used = std::min(P, batches.size());
     for (size_t p = 0; p < used; p++) {
-        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
+        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u), overlap);
         if (rc != RTX_OK) return rc;
     }
     rc = ensure_pixels(c, pt.npix, want_f32);
@@ -523,6 +534,8 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     c->stream = c->pipes[0].main;
     c->persistent_blocks = query_persistent_blocks(device);
+    if (const char *pb = std::getenv("RTX_PERSISTENT_BLOCKS"))  // tests: grids whose wave count is not a multiple of QPARTS
+        if (std::atoi(pb) > 0) c->persistent_blocks = std::atoi(pb);
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
     if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: never, 1: always
@@ -575,6 +588,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     c->has_scene = false;
     c->info = rtx_bvh_info{};
     int threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (c->build_threads > 0) threads = c->build_threads;
     if (const char *t = std::getenv("RTX_BUILD_THREADS")) threads = std::max(1, std::atoi(t));
     double t0 = now_s();
     BuiltBvh bvh;
@@ -588,6 +602,10 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if (bvh.depth + 2 > (uint32_t)MAX_TREE_DEPTH || 3 * fs.wide_depth + 2 > (uint32_t)MAX_TREE_DEPTH) {
         c->err = "BVH deeper than the traversal stack";
         return RTX_ERR_CAPACITY;
+    }
+    {
+        const uint32_t need = std::max(bvh.depth, 3 * fs.wide_depth) + 2;
+        c->spill_entries = need > (uint32_t)LDS_STACK ? need - (uint32_t)LDS_STACK : 1u;
     }
     double t2 = now_s();
     DeviceScene &ds = c->ds;
@@ -634,6 +652,12 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     c->info.flatten_seconds = t2 - t1;
     c->info.upload_seconds = t3 - t2;
     c->has_scene = true;
+    return RTX_OK;
+}
+
+int rtx_set_build_threads(rtx_ctx *c, int threads) {
+    if (!c || threads < 0 || threads > 1024) return RTX_ERR_INVALID;
+    c->build_threads = threads;
     return RTX_OK;
 }
 

@@ -426,6 +426,47 @@ def test_cli_renders_the_same_png(rt, gpu, tmp_path):
     assert subprocess.call([exe, "--no-such-flag"], stderr=subprocess.DEVNULL) == 2
 
 
+def test_cli_non_square_scene_file(rt, gpu, tmp_path):
+    """A scene file with its own `size W H`: the CLI's PNG has the camera's size, not -w squared
+    (rtx_render_builtin_to_png once sized its buffer width x width: heap overflow / scrambled rows)."""
+    import subprocess
+    src = open(os.path.join(rt.MEDIA_DIR, "scenes", "basic.scene")).read()
+    scene = tmp_path / "wide.scene"
+    scene.write_text(src + "\nsize 120 56\n")   # (its texture is named media:texture.png: found through --media)
+    exe = os.path.join(os.path.dirname(rt.__file__), "rtx-render")
+    out = str(tmp_path / "wide.png")
+    subprocess.check_call([exe, "-f", out, "-w", "40", "-s", "1", "-b", "2", "--scene", "file:" + str(scene),
+                           "--media", rt.MEDIA_DIR])
+    img_cli = rt.png_read(out)
+    s = rt.HostScene("file:" + str(scene), 40)
+    assert (s.width, s.height) == (120, 56)
+    gpu.upload(s)
+    img, _ = gpu.render(spp=1, bounces=2)
+    assert img.shape == (56, 120, 3)
+    assert img_cli.shape == img.shape and np.array_equal(img_cli, img)
+
+
+def test_odd_persistent_grids_trace_every_ray(rt, gpu, monkeypatch):
+    """Grids whose wave count is not a multiple of the 16 sub-queues (37 or 3 blocks): every
+    statically dealt queue chunk must still have an owner -- same bytes, same ray counts."""
+    s = rt.HostScene("basic_suzanne", 160)
+    gpu.upload(s)
+    ref, st0 = gpu.render(spp=3, bounces=4, seed=11)
+    obj0, t0 = gpu.trace_primary()
+    for blocks in ("37", "3", "1"):
+        monkeypatch.setenv("RTX_PERSISTENT_BLOCKS", blocks)
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            img, st = c.render(spp=3, bounces=4, seed=11)
+            obj, t = c.trace_primary()
+        finally:
+            c.close()
+        assert st.rays == st0.rays, f"{blocks} blocks: {st.rays} rays instead of {st0.rays}"
+        assert np.array_equal(img, ref), f"{blocks} blocks: {(img != ref).sum()} bytes differ"
+        assert np.array_equal(obj, obj0) and np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+
+
 def test_ply_mesh_scene_matches_oracle(rt, orc, gpu, tmp_path):
     """A binary PLY (the Stanford scans' format, README.md:7) through mesh:<path>: a displaced
     UV sphere of triangles with quad caps rows, traced and shaded like any other scene."""
