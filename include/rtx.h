@@ -156,6 +156,19 @@ int rtx_render(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
 int rtx_render_device(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
                       const rtx_partition *part_or_null, uint32_t flags,
                       void *d_tiles_rgb8, rtx_stats *stats_or_null);
+/* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result bytes as
+ * rtx_render_device, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no event:
+ * the wavefront state of the render (path nodes, shadow queues, counters, queue heads, stack spill,
+ * pixel sums) lives in a static 64 MiB device array that each GPU holds from library load to process
+ * end.  The render runs as ONE batch on a reduced grid, serially on rtx_stream(), asynchronously
+ * (rtx_synchronize to wait); no stats.  A render whose state does not fit -- roughly
+ * pixel slots x spp x 72 B x (bounce levels actually reachable) plus 5-20 MiB of stack spill --
+ * is rejected with RTX_ERR_CAPACITY and rtx_last_error says how much it needed.  All contexts of
+ * one GPU share the array: calls that overlap on one GPU (two contexts, or a second call before
+ * the first has finished on another stream) race; calls in sequence on one context are ordered. */
+int rtx_render_device_noalloc(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
+                              const rtx_partition *part_or_null, uint32_t flags, void *d_tiles_rgb8);
 /* Number of pixel slots (tiles * tile * tile) this rank owns under `part`. */
 uint64_t rtx_partition_pixels(rtx_ctx *ctx, const rtx_partition *part_or_null);
 void *rtx_stream(rtx_ctx *ctx); /* hipStream_t the kernels are launched on */

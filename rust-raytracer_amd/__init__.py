@@ -97,6 +97,7 @@ def lib():
                              C.POINTER(Stats)]
     L.rtx_render_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32, vp,
                                     C.POINTER(Stats)]
+    L.rtx_render_device_noalloc.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32, vp]
     L.rtx_set_build_threads.argtypes = [vp, C.c_int]
     L.rtx_partition_pixels.argtypes = [vp, C.POINTER(Partition)]
     L.rtx_partition_pixels.restype = C.c_uint64
@@ -361,6 +362,11 @@ class Context:
         self._check(lib().rtx_render_device(self._h, spp, bounces, seed, p, flags, C.c_void_p(d_ptr),
                                             C.byref(st) if stats else None))
         return st
+
+    def render_device_noalloc(self, d_ptr, spp=1, bounces=4, seed=0, part=None, flags=0):
+        """rtx_render_device_noalloc: wavefront state in the library's static device array (asynchronous)."""
+        p = C.byref(Partition(*part)) if part else None
+        self._check(lib().rtx_render_device_noalloc(self._h, spp, bounces, seed, p, flags, C.c_void_p(d_ptr)))
 
     def set_build_threads(self, n):
         self._check(lib().rtx_set_build_threads(self._h, n))

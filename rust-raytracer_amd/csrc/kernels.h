@@ -112,4 +112,11 @@ void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const L
 void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc);
 int query_persistent_blocks(int device);
 
+// rtx_render_device_noalloc: the wavefront state of a small render lives in a file-scope
+// `static __device__` array (kernels.hip) instead of hipMalloc'ed buffers.  Every GPU holds its
+// own copy at its own address: noalloc_scratch_address looks it up (hipGetSymbolAddress) with
+// `device` current, once per device, and caches it.
+constexpr size_t NOALLOC_SCRATCH_BYTES = 64ull << 20;
+hipError_t noalloc_scratch_address(int device, void **ptr);
+
 }  // namespace rtx

@@ -16,6 +16,26 @@
 
 namespace rtx {
 
+// Scratch of rtx_render_device_noalloc (path nodes, shadow queues, counters, queue heads, stack
+// spill, pixel sums of one small render).  In host code this name is only a handle for
+// hipGetSymbolAddress: kernels and memsets get the address that noalloc_scratch_address returns.
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+hipError_t noalloc_scratch_address(int device, void **ptr) {
+    constexpr int MAX_DEVICES = 64;
+    static void *cached[MAX_DEVICES] = {};
+    *ptr = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!cached[device]) {  // the caller has made `device` current (rtx_init)
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        cached[device] = p;
+    }
+    *ptr = cached[device];
+    return hipSuccess;
+}
+
 namespace {
 
 constexpr int BLOCK = 256;

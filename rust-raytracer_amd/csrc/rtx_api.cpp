@@ -65,6 +65,7 @@ struct rtx_ctx {
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
     int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
+    uint8_t *scratch = nullptr;       // this device's copy of the static scratch array (rtx_render_device_noalloc)
     uint64_t overlap_below = ~0ull;  // renders with fewer primary samples run their kernels concurrently (RTX_CONCURRENT=0: none)
 };
 
@@ -156,6 +157,31 @@ uint64_t geo_last(uint32_t K, uint32_t levels) {
     for (uint32_t k = 1; k < levels; k++) g *= K;
     if (levels > 1 && K == 0) return 1;
     return std::max<uint64_t>(g, 1);
+}
+
+// Lays the wavefront buffers of one batch (`n0` primary samples traced `levels` deep, `threads`
+// persistent threads, `npix` pixel sums) out in [base, ...) and returns the bytes used; with
+// base == nullptr it only measures.  Used for the static scratch of rtx_render_device_noalloc.
+size_t layout_frame(uint8_t *base, uint64_t node_cap, uint64_t q_cap, uint32_t levels, uint32_t nl, size_t threads,
+                    uint32_t spill_entries, uint64_t npix, Frame &fr, float4 **sum) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> uint8_t * {
+        uint8_t *p = base ? base + off : nullptr;
+        off += (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
+        return p;
+    };
+    fr.ray_o = (float4 *)take(node_cap * sizeof(float4));
+    fr.ray_d = (float4 *)take(node_cap * sizeof(float4));
+    fr.link = (uint2 *)take(node_cap * sizeof(uint2));
+    fr.color = (float4 *)take(node_cap * sizeof(float4));
+    fr.shadow_q = (uint32_t *)take((size_t)levels * nl * q_cap * sizeof(uint32_t));
+    fr.counters = (uint32_t *)take(CTR_WORDS * sizeof(uint32_t));
+    fr.work = (uint32_t *)take(WORK_WORDS * sizeof(uint32_t));
+    fr.spill = (uint32_t *)take(threads * spill_entries * sizeof(uint32_t) * 2);
+    *sum = (float4 *)take(npix * sizeof(float4));
+    fr.node_cap = (uint32_t)node_cap;
+    fr.q_cap = (uint32_t)q_cap;
+    return off;
 }
 
 // Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep
@@ -536,6 +562,13 @@ int rtx_init(int device, rtx_ctx **out) {
     c->persistent_blocks = query_persistent_blocks(device);
     if (const char *pb = std::getenv("RTX_PERSISTENT_BLOCKS"))  // tests: grids whose wave count is not a multiple of QPARTS
         if (std::atoi(pb) > 0) c->persistent_blocks = std::atoi(pb);
+    // this device's copy of the static scratch array of rtx_render_device_noalloc, looked up once, here
+    e = noalloc_scratch_address(device, (void **)&c->scratch);
+    if (e != hipSuccess || !c->scratch) {
+        g_init_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+        rtx_destroy(c);
+        return RTX_ERR_HIP;
+    }
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
     if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: never, 1: always
@@ -702,6 +735,77 @@ int rtx_render_device(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed,
     if (!c || !d_tiles) return RTX_ERR_INVALID;
     Partition pt;
     return render_impl(c, spp, bounces, seed, part, flags, d_tiles, false, stats, pt);
+}
+
+int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
+                              uint32_t flags, void *d_tiles) {
+    if (!c || !d_tiles) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    if (spp == 0) {
+        c->err = "samples_per_pixel must be non-zero (world.rs:30)";
+        return RTX_ERR_INVALID;
+    }
+    if (bounces > 8) {
+        c->err = "max_ray_bounces > 8 not supported";
+        return RTX_ERR_CAPACITY;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    Partition pt;
+    int rc = make_partition(c, part, pt);
+    if (rc != RTX_OK) return rc;
+    // ONE batch whose wavefront buffers are carved out of the static scratch array; a grid of at
+    // most one block per CU keeps the stack-spill part of it small
+    const uint32_t levels = bounces, lv = std::max(levels, 1u), K = c->max_bounce;
+    const uint32_t nl = std::max<uint32_t>(c->ds.n_lights, 1);
+    const int blocks = std::min(c->persistent_blocks, 256);
+    const uint64_t n0 = std::max<uint64_t>(pt.npix * spp, 1);
+    const long double est = (long double)n0 * (long double)geo_sum(K, lv);
+    Pipe np;  // no streams or events of its own: the serial schedule on rtx_stream()
+    float4 *sum = nullptr;
+    size_t need = ~(size_t)0;
+    if (est < 4.0e9L)
+        need = layout_frame(c->scratch, n0 * geo_sum(K, lv), n0 * geo_last(K, lv), lv, nl, (size_t)blocks * 256,
+                            c->spill_entries, pt.npix, np.fr, &sum);
+    if (need > NOALLOC_SCRATCH_BYTES) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg,
+                      "rtx_render_device_noalloc: %llu pixel slots x %u spp, %u bounces need %.1f MiB of wavefront state; the "
+                      "static scratch holds %.0f MiB (use rtx_render_device)",
+                      (unsigned long long)pt.npix, spp, bounces, est < 4.0e9L ? need / 1048576.0 : 1e9,
+                      NOALLOC_SCRATCH_BYTES / 1048576.0);
+        c->err = msg;
+        return RTX_ERR_CAPACITY;
+    }
+    np.main = c->stream;
+    flags |= c->force_flags;
+    LaunchCfg lc{c->stream, blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    BatchInfo info{};
+    info.q0 = 0;
+    info.npix = (uint32_t)pt.npix;
+    info.s0 = 0;
+    info.ns = spp;
+    info.spp = spp;
+    info.use_jitter = spp != 1;  // world.rs:47-51
+    info.seed_lo = (uint32_t)seed;
+    info.seed_hi = (uint32_t)(seed >> 32);
+    info.tile = pt.tile;
+    info.rank = pt.rank;
+    info.nranks = pt.nranks;
+    info.tiles_x = pt.tiles_x;
+    info.tiles_y = pt.tiles_y;
+    info.max_levels = levels;
+    // the array keeps the previous call's contents: counters and queue heads must start at zero
+    rc = reset_counters(c, np);
+    if (rc != RTX_OK) return rc;
+    launch_raygen(c->ds, np.fr, info, lc);
+    rc = run_levels(c, np, lc, levels, false, 0, false);
+    if (rc != RTX_OK) return rc;
+    launch_accumulate(c->ds, np.fr, info, sum, static_cast<uint8_t *>(d_tiles), nullptr, lc);
+    HIP_TRY(c, hipGetLastError());
+    return RTX_OK;
 }
 
 int rtx_render(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part, uint32_t flags,
