@@ -133,48 +133,35 @@ def main():
         rt.png_write(args.out, img.cpu().numpy())
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_step * args.steps / elapsed / 1e6
-    # Dominant kernel of rank 0 = the BVH traversal, instantiated as trace_closest and trace_shadow.
-    # The launches of one step run concurrently on several streams (shadow rays of a bounce level
-    # beside the next level's closest-hit rays), so their individual event spans overlap and share
-    # the GPU; the traversal is therefore timed as ONE span per step -- HIP events on the library's
-    # streams from the first trace launch's start to the last one's end -- and priced with the
-    # algorithmic bytes of all of the step's trace launches.  The per-kernel spans are kept below.
-    c_ms = sum(s.closest_kernel_ms for s in stats)
-    s_ms = sum(s.shadow_kernel_ms for s in stats)
-    c_l = sum(s.closest_launches for s in stats)
-    s_l = sum(s.shadow_launches for s in stats)
-    span_ms = sum(s.trace_span_ms for s in stats) / args.steps
+    # Dominant kernel of rank 0 = the persistent path kernel: ONE launch per batch traces every ray of
+    # every bounce level (closest-hit and shadow queries), timed with HIP events on the library's
+    # stream (rtx_stats.path_kernel_ms) inside the timed region.
+    p_ms = sum(s.path_kernel_ms for s in stats)
+    p_l = sum(s.path_launches for s in stats)
+    r_ms = sum(s.resolve_ms for s in stats) / args.steps
+    avg_launch_ms = p_ms / max(p_l, 1)
+    launches_per_step = p_l / args.steps
     c_rays = counted.primary_rays + counted.bounce_rays
     s_rays = counted.shadow_rays
     c_bytes = NODE_BYTES * counted.closest_nodes + PRIM_BYTES * counted.closest_prims + RAY_IO_BYTES * c_rays
     s_bytes = NODE_BYTES * counted.shadow_nodes + PRIM_BYTES * counted.shadow_prims + RAY_IO_BYTES * s_rays
     t_bytes, t_rays = c_bytes + s_bytes, c_rays + s_rays
-    achieved = t_bytes / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0
+    bytes_per_launch = t_bytes / max(launches_per_step, 1)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # written by tests/pmc_summary.py from the rocprofv3 --pmc passes
-    if os.path.exists(tpath) and args.scene == "scan" and args.tris == 0 and args.width == 1024 and args.spp == 16 and world == 1:
-        tj = json.load(open(tpath))
-        tc, ts = tj.get("trace_closest_kernel<false, false>"), tj.get("trace_shadow_kernel<false, false>")
-        if tc and ts:
-            traffic = int(tc["fetch_bytes_per_launch"] * c_l / args.steps + ts["fetch_bytes_per_launch"] * s_l / args.steps)
 
-    def per_kernel(ms, launches, nbytes, rays):
-        per_step = ms / args.steps
-        return {"launches_per_step": launches / args.steps, "span_ms_per_step": round(per_step, 4),
-                "algorithmic_bytes_per_step": int(nbytes), "rays_per_step": int(rays),
-                "bytes_per_ray": round(nbytes / max(rays, 1), 1),
-                "GB/s_over_own_spans": round(nbytes / max(per_step * 1e-3, 1e-12) / 1e9, 2)}
+    def per_class(nbytes, rays, nodes, prims):
+        return {"rays_per_step": int(rays), "algorithmic_bytes_per_step": int(nbytes), "bytes_per_ray": round(nbytes / max(rays, 1), 1),
+                "nodes_per_ray": round(nodes / max(rays, 1), 3), "prims_per_ray": round(prims / max(rays, 1), 3)}
 
-    roofline = {"bound": "hbm", "kernel": "trace (trace_closest + trace_shadow launches of a step, concurrent: one span)",
+    roofline = {"bound": "hbm", "kernel": "path_kernel (closest-hit + shadow queries of all bounce levels, one persistent launch per batch)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(t_bytes), "avg_launch_ms": round(span_ms, 4), "launches_per_step": 1,
-                "physical_launches_per_step": (c_l + s_l) / args.steps, "rays_per_step": int(t_rays),
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
+                "launches_per_step": launches_per_step, "resolve_ms_per_step": round(r_ms, 4), "rays_per_step": int(t_rays),
                 "bytes_per_ray": round(t_bytes / max(t_rays, 1), 1),
-                "visits_per_step": {"closest_nodes": int(counted.closest_nodes), "closest_prims": int(counted.closest_prims),
-                                    "shadow_nodes": int(counted.shadow_nodes), "shadow_prims": int(counted.shadow_prims)},
-                "per_kernel": {"trace_closest": per_kernel(c_ms, c_l, c_bytes, c_rays),
-                               "trace_shadow": per_kernel(s_ms, s_l, s_bytes, s_rays)}}
+                "per_class": {"closest": per_class(c_bytes, c_rays, counted.closest_nodes, counted.closest_prims),
+                              "shadow": per_class(s_bytes, s_rays, counted.shadow_nodes, counted.shadow_prims)}}
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

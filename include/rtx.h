@@ -90,16 +90,16 @@ typedef struct rtx_stats {
     /* records fetched, per kernel class; 0 unless RTX_FLAG_COUNT_VISITS is set.  Nodes are the
      * 128-byte four-slot nodes (64-byte binary nodes under RTX_FLAG_REFERENCE_TRAVERSAL),
      * primitives 64-byte records. */
-    uint64_t closest_nodes, closest_prims;  /* trace_closest: internal nodes, primitive records */
-    uint64_t shadow_nodes, shadow_prims;    /* trace_shadow */
-    double trace_ms;            /* host wall time raygen..resolve (stream-synchronised) */
-    double closest_kernel_ms;   /* HIP-event time summed over trace_closest launches */
-    double shadow_kernel_ms;    /* HIP-event time summed over trace_shadow launches (launches that run
-                                   concurrently share the GPU: the sums can exceed the wall time) */
-    double trace_span_ms;       /* HIP-event time from the first trace launch's start to the last one's end */
-    uint32_t closest_launches, shadow_launches;
+    uint64_t closest_nodes, closest_prims;  /* closest-hit rays: internal nodes, primitive records */
+    uint64_t shadow_nodes, shadow_prims;    /* shadow queries */
+    double trace_ms;            /* host wall time raygen..accumulate (stream-synchronised) */
+    double path_kernel_ms;      /* HIP-event time of the persistent path kernel, summed over the batches
+                                   (one launch per batch: every ray of every bounce level) */
+    double resolve_ms;          /* HIP-event time of the resolve passes behind it, summed over the batches */
+    uint32_t path_launches;
     uint32_t batches;
     uint32_t max_ray_records;   /* most node + primitive records visited by one ray (COUNT_VISITS) */
+    uint32_t reserved;
 } rtx_stats;
 
 /* BVH facts after upload (bvh.rs:18-24 logs the same numbers). */

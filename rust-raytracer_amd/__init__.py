@@ -47,10 +47,9 @@ class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64),
                 ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64),
-                ("trace_ms", C.c_double), ("closest_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
-                ("trace_span_ms", C.c_double),
-                ("closest_launches", C.c_uint32), ("shadow_launches", C.c_uint32),
-                ("batches", C.c_uint32), ("max_ray_records", C.c_uint32)]
+                ("trace_ms", C.c_double), ("path_kernel_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("path_launches", C.c_uint32), ("batches", C.c_uint32), ("max_ray_records", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     @property
     def rays(self):

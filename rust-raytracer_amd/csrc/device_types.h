@@ -91,7 +91,9 @@ struct LightRec {
     float dir[3];
     float angle_deg;
     float color[3];
-    uint32_t pad;
+    // Cone lights: cos of the cut-off angle, for the cheap pre-filter in front of the reference's
+    // atan2 comparison (light.rs:113-116); 2 = always outside, -2 = never outside (cut-off >= pi).
+    float cos_cut;
 };
 
 enum : uint32_t { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTIONAL = 2, LIGHT_CONE = 3 };  // light.rs:12-17

@@ -358,7 +358,13 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             l.color[k] = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
         }
         l.angle_deg = d.light_angle_deg[i];
-        l.pad = 0;
+        {   // the kernels compare atan2(...) > angle_deg * (pi/180) in f32; cos of that same f32 value
+            const float cut = l.angle_deg * (float)(3.14159265358979323846 / 180.0);
+            if (!(cut == cut)) l.cos_cut = 0.0f;          // NaN: every comparison is false -> the exact path decides
+            else if (cut < 0.0f) l.cos_cut = 2.0f;        // angle >= 0 > cut: always outside
+            else if (cut >= 3.14159265f) l.cos_cut = -2.0f;  // angle <= pi <= cut: never outside
+            else l.cos_cut = (float)std::cos((double)cut);
+        }
     }
     // primitives in leaf order
     uint32_t n = d.n_objects;

@@ -20,6 +20,7 @@ struct DeviceScene {
     const LightRec *lights;
     const uint32_t *prim_obj;   // leaf-order primitive -> object index of the description
     uint32_t n_prims, n_lights, n_wnodes;
+    uint32_t max_bounce;        // most bounce children any material spawns per hit
     uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
     uint32_t wroot_ref;         // root in the wide tree (wide node 0 or the root leaf)
     uint32_t xf0_identity;      // transform 0 is exactly the identity
@@ -33,44 +34,55 @@ struct DeviceScene {
 
 // Counter block (uint32 words) in device memory, zeroed before every batch.
 enum {
-    CTR_LEVEL_COUNT = 0,    // [8]  path nodes per bounce level
-    CTR_SHADOW_COUNT = 8,   // [8][MAX_LIGHTS] shadow-queue entries per level and light
-    CTR_OVERFLOW = 8 + 8 * MAX_LIGHTS,
-    CTR_VISIT_NODES_LO = CTR_OVERFLOW + 2,  // trace_closest: 64-bit counters as lo/hi pairs (8-byte aligned)
+    CTR_LEVEL_COUNT = 0,    // primary samples of the batch (written by raygen / load_rays)
+    CTR_POOL = 1,           // path nodes handed out from the pool of bounce children (in runs of POOL_RUN)
+    CTR_OVERFLOW = 2,
+    CTR_BOUNCE_LO = 4,      // 64-bit counters as lo/hi pairs (8-byte aligned): bounce rays traced,
+    CTR_BOUNCE_HI,
+    CTR_SHADOW_LO,          // shadow queries traced,
+    CTR_SHADOW_HI,
+    CTR_VISIT_NODES_LO,     // records visited by closest-hit rays (COUNT)
     CTR_VISIT_NODES_HI,
     CTR_VISIT_PRIMS_LO,
     CTR_VISIT_PRIMS_HI,
-    CTR_SVISIT_NODES_LO,                    // trace_shadow
+    CTR_SVISIT_NODES_LO,    // ... by shadow rays
     CTR_SVISIT_NODES_HI,
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
-    CTR_MAX_STEPS,                          // most records visited by a single ray (COUNT)
-    CTR_UTIL = 148,                         // [2][5] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
-    CTR_WORDS = 168
+    CTR_MAX_STEPS,          // most records visited by a single ray (COUNT)
+    CTR_UTIL = 20,          // [5] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
+    CTR_WORDS = 32
 };
-// Queue heads of the persistent trace kernels live in their own buffer (Frame::work): per
-// bounce level WORK_QUEUES queues (0 = trace_closest, 1 + l = trace_shadow of light l), each
-// split into QPARTS sub-queues whose head counters sit on separate 128-byte lines -- one
-// hot counter sustains only ~90 atomics/us, which bounds small frames (multi-GPU shares).
+// Queue heads of the persistent path kernel live in their own buffer (Frame::work): the batch's
+// primary samples are ONE queue split into QPARTS sub-queues whose head counters sit on separate
+// 128-byte lines -- one hot counter sustains only ~90 atomics/us, which bounds small frames
+// (multi-GPU shares).
 enum {
-    WORK_QUEUES = 1 + MAX_LIGHTS,
     QPARTS = 16,
     QHEAD_STRIDE = 32,  // words
-    WORK_WORDS = 8 * WORK_QUEUES * QPARTS * QHEAD_STRIDE
+    WORK_WORDS = QPARTS * QHEAD_STRIDE,
+    POOL_RUN = 128,     // bounce-child path nodes a wave reserves with one atomic
+    SHADE_LIST = 192    // hits a wave can have waiting for its shading pass (behind its work stack)
 };
-static_assert(CTR_VISIT_NODES_LO % 2 == 0 && CTR_MAX_STEPS < CTR_WORDS, "64-bit counters must be 8-byte aligned");
+static_assert(CTR_BOUNCE_LO % 2 == 0 && CTR_MAX_STEPS < CTR_UTIL && CTR_UTIL + 10 <= CTR_WORDS, "64-bit counters must be 8-byte aligned");
 
-// Wavefront state of one batch of primary samples ("path nodes": one per traced ray).
+// link.x of a path node: bits 15..0 mask of the lights that reach the hit point, 19..16 bounce
+// level, 22..20 number of bounce children; link.y first bounce child (NO_PRIM: none).
+constexpr uint32_t LINK_LEVEL_SHIFT = 16, LINK_NB_SHIFT = 20, LINK_LEVEL_HOLE = 15;
+
+// Wavefront state of one batch of primary samples ("path nodes": one per traced closest-hit ray).
+// Nodes [0, n0) are the primary samples; bounce children live in the pool [n0, node_cap), handed
+// out to the waves in runs (unused slots of a run are marked as holes when the wave retires).
 struct Frame {
     float4 *ray_o;      // xyz origin,    w = hit t
     float4 *ray_d;      // xyz direction, w = bits of hit primitive (leaf order)
-    uint2 *link;        // x = lit-light mask, y = first bounce child (NO_PRIM: none)
+    uint2 *link;        // see LINK_*
     float4 *color;      // resolved colour of the node
-    uint32_t *shadow_q; // [level][n_lights][q_cap] node ids waiting for a shadow query
+    uint2 *wstack;      // [wave][wstack_cap + SHADE_LIST] work stacks of the path kernel's waves (node, tag)
     uint32_t *counters; // CTR_WORDS
     uint32_t *work;     // WORK_WORDS queue heads
-    uint32_t *spill;    // traversal-stack overflow, [MAX_TREE_DEPTH-LDS_STACK][threads] of (ref, t)
-    uint32_t node_cap, q_cap;
+    uint32_t *spill;    // traversal-stack overflow, [spill entries][threads] of (ref, t)
+    uint32_t node_cap, wstack_cap;
 };
 
 struct BatchInfo {
@@ -85,30 +97,30 @@ struct BatchInfo {
 
 struct LaunchCfg {
     hipStream_t stream;
-    int persistent_blocks;  // grid of the persistent trace kernels
+    int persistent_blocks;  // grid of the persistent path kernel
     bool count_visits;
     bool reference_traversal;
 };
 
 void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, const LaunchCfg &lc);
-void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
-void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level, uint32_t max_levels,
-                          const LaunchCfg &lc);
-void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
-// Resolves the colours of a level's path nodes (material.rs:118-206).  RESOLVE_LEAVES: misses
-// and hits without bounce children (ready once the level's shadow answers exist);
-// RESOLVE_PARENTS: hits with bounce children (need the deeper levels); RESOLVE_ALL: both.
-enum ResolvePhase : uint32_t { RESOLVE_ALL = 0, RESOLVE_LEAVES = 1, RESOLVE_PARENTS = 2 };
-void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, ResolvePhase phase, const LaunchCfg &lc);
+// Loads caller rays (origin, direction) as the batch's primaries, normalising as Ray::new does.
+void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc);
+// The trace path of the batch's primaries in ONE persistent launch: a lane takes a primary from the
+// queue and follows World::trace_ray (world.rs:115-131) through its whole path tree, depth-first:
+// closest hit, the shadow query of every light (light.rs:81-122), the bounce rays of
+// material.rs:185-203 -- each of them a path node whose record the resolve pass reads.
+// shade == false: closest hits of the primaries only (rtx_trace_primary / rtx_trace_rays).
+void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc);
+// Resolves the colours of the path nodes of one bounce level (material.rs:118-206), deepest level
+// first: a node's bounce children have their colours by then.
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);
 // Adds the batch's sample colours to `sum` in sample order (world.rs:54-61); on the last
 // sample chunk divides by spp, clamps and quantises (world.rs:62-63, color.rs:25-31).
 void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum,
                        uint8_t *tiles_rgb8, float *tiles_f32_or_null, const LaunchCfg &lc);
-// Hit export for rtx_trace_primary / rtx_trace_rays: level-0 nodes -> (object id, t).
+// Hit export for rtx_trace_primary / rtx_trace_rays: primaries -> (object id, t).
 void launch_export_hits(const DeviceScene &sc, const Frame &fr, uint32_t n, uint32_t *out_obj, float *out_t,
                         const LaunchCfg &lc);
-// Loads caller rays (origin, direction) into level 0, normalising as Ray::new does.
-void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc);
 void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc);
 int query_persistent_blocks(int device);
 

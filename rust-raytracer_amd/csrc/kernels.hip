@@ -4,11 +4,11 @@
 // come out bit-identical; only libm calls (atan2/acos/pow) differ in the last ulp.
 //
 //   raygen          camera.rs:32-47 + the spp loop of world.rs:54-61
-//   trace_closest   bvh.rs:60-131,359-395 + object.rs:145-220   (persistent, per-lane stack in LDS)
-//   shade_forward   world.rs:118-125 (hit point, shadow-ray list) + material.rs:185-203 (bounce rays),
-//                   queues compacted with wave ballot / prefix sum
-//   trace_shadow    light.rs:81-122 as an any-hit query
-//   resolve         material.rs:53-76,98-206,220-240 + color.rs (clamped algebra), bottom-up
+//   path            World::trace_ray (world.rs:115-131) for a queue of primary samples in ONE persistent
+//                   launch: per lane, depth-first through the sample's path tree -- closest hit
+//                   (bvh.rs:60-131,359-395 + object.rs:145-220), one any-hit shadow query per light
+//                   (light.rs:81-122), the bounce rays of material.rs:185-203; per-lane stack in LDS
+//   resolve         material.rs:53-76,98-206,220-240 + color.rs (clamped algebra), bottom-up per level
 //   accumulate      world.rs:61-63 + color.rs:25-31
 #include "kernels.h"
 
@@ -148,12 +148,6 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t *head, uint32_t n) {
     uint32_t b = 0;
     if (lane_id() == 0) b = atomicAdd(head, n);
     return __builtin_amdgcn_readfirstlane(b);
-}
-
-__device__ __forceinline__ uint32_t level_base(const uint32_t *ctr, uint32_t level) {
-    uint32_t b = 0;
-    for (uint32_t j = 0; j < level; j++) b += ctr[CTR_LEVEL_COUNT + j];
-    return b;
 }
 
 // ---------------------------------------------------------------- ray state for traversal
@@ -366,11 +360,12 @@ __device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const 
 }
 
 // ---------------------------------------------------------------- BVH traversal
-// MODE 0: closest hit, ties resolved by (t, leaf-order index) = the reference's
-//         "first minimum wins" over its left-to-right recursion (bvh.rs:367-371,385-389).
-// MODE 1: light.rs:81-97 as any-hit: stop at the first hit with t + 1e-4 < dist;
-//         otherwise report whether anything was hit at all.
-// MODE 2: directional light (light.rs:106-112): stop at the first hit.
+// A lane's query is one of two kinds (per lane, at run time):
+// closest: closest hit, ties resolved by (t, leaf-order index) = the reference's "first minimum
+//          wins" over its left-to-right recursion (bvh.rs:367-371,385-389).
+// shadow:  light.rs:81-97 as any-hit: stop at the first hit with t + 1e-4 < dist; otherwise report
+//          whether anything was hit at all.  A directional light (light.rs:106-112: any hit at all
+//          blocks) is the same query with dist = infinity.
 constexpr uint32_t TRAV_DONE = 0xFFFFFFFFu;  // has LEAF_BIT set: ends the descent loop
 
 // Per-lane traversal stack: LDS_STACK entries of (node reference, entry t) in LDS, laid
@@ -442,15 +437,14 @@ struct Trav {
     uint32_t cur;
     float limit_plus;
     uint32_t prim;
-    float t;
+    float t;                // closest: best hit so far; shadow: distance light -> shaded point
     bool any, occluded;
-    uint32_t nodes, prims;  // visit counters, accumulated over the lane's rays (COUNT)
+    uint32_t nodes, prims;  // visit counters of the lane's current ray (COUNT)
 };
 
 template <bool REF, bool OVH>
 __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack &st) {
     s.prim = NO_PRIM;
-    s.t = INFINITY;
     s.any = false;
     s.occluded = false;
     s.limit_plus = INFINITY;
@@ -603,21 +597,22 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
 
 // Advances a lane that holds a leaf by ONE primitive (Vec order, bvh.rs:378-389): the leaf
 // reference (first << 3 | count) shrinks from the front until it is used up.
-template <int MODE, bool COUNT, bool REF>
-__device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack &st, float dist) {
+template <bool COUNT, bool REF>
+__device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow) {
     uint32_t cur = s.cur;
     uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
     float tw;
     if (COUNT) s.prims++;
     if (prim_intersect(sc.prims + first, s.r, sc.xforms, tw)) {
-        if (MODE == 0) {
+        if (!shadow) {
             if (!s.any || tw < s.t || (tw == s.t && first < s.prim)) {
                 s.any = true;
                 s.t = tw;
                 s.prim = first;
                 if (!REF) s.limit_plus = tw + (s.r.slack0 + 1.5e-5f * fabsf(tw));
             }
-        } else if (MODE == 1) {
+        } else {
+            const float dist = s.t;
             s.any = true;
             if (tw + 1e-4f < dist) {
                 s.occluded = true;
@@ -625,11 +620,6 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
                 return;
             }
             if (!REF) s.limit_plus = dist + (s.r.slack0 + 1.5e-5f * fabsf(dist));
-        } else {
-            s.any = true;
-            s.occluded = true;
-            s.cur = TRAV_DONE;
-            return;
         }
     }
     s.cur = ((cur & 7u) > 1u) ? cur + 7u : st.pop(s.limit_plus);  // first + 1, count - 1
@@ -660,8 +650,8 @@ struct Util {
     }
 };
 
-template <int MODE, bool COUNT, bool REF, bool OVH>
-__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, float dist, LdsNodePtr lds_top,
+template <bool COUNT, bool REF, bool OVH>
+__device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow, LdsNodePtr lds_top,
                                           Util &u) {
     bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
     bool at_node = !(s.cur & LEAF_BIT);
@@ -674,7 +664,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
         u.prim_steps++;
         u.prim_lanes += nl;
 #endif
-        if (at_leaf) prim_step<MODE, COUNT, REF>(sc, s, st, dist);
+        if (at_leaf) prim_step<COUNT, REF>(sc, s, st, shadow);
     } else {
 #ifdef RTX_UTIL_STATS
         u.node_steps++;
@@ -690,7 +680,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 // one: as soon as REFILL_MIN lanes have finished their ray they get new rays, so lanes do
 // not idle until the longest ray of a 64-ray batch is done.
 #ifndef RTX_REFILL_MIN
-#define RTX_REFILL_MIN 16
+#define RTX_REFILL_MIN 32
 #endif
 struct WaveQueue {
     uint32_t *heads;
@@ -824,92 +814,6 @@ __global__ void __launch_bounds__(BLOCK) load_rays_kernel(Frame fr, const float 
     fr.ray_d[i] = make_float4(d.x, d.y, d.z, __uint_as_float(NO_PRIM));
 }
 
-// ---------------------------------------------------------------- trace_closest
-template <bool COUNT, bool REF, bool OVH>
-__device__ __forceinline__ void trace_closest_body(const DeviceScene &sc, const Frame &fr, uint32_t level) {
-    __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
-    __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
-    const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
-    if (TOP_NODES != 0u && !REF) {
-        for (uint32_t i = threadIdx.x; i < TOP_NODES * 7u; i += TBLOCK) {
-            uint32_t piece = i / (TOP_NODES ? TOP_NODES : 1u), n = i % (TOP_NODES ? TOP_NODES : 1u);
-            lds_top_store[i] = n < sc.n_wnodes ? reinterpret_cast<const v4f *>(sc.wnodes + n)[piece] : v4f{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-    }
-    const uint32_t base = level_base(fr.counters, level);
-    const uint32_t nthreads = gridDim.x * TBLOCK;
-    const uint32_t gtid = blockIdx.x * TBLOCK + threadIdx.x;
-    Stack st;
-    st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
-    st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
-    st.spill_stride = nthreads;
-    st.sp = 0;
-    Trav s;
-    s.cur = TRAV_DONE;
-    s.nodes = s.prims = 0;
-    uint32_t node = 0;
-    uint32_t ray_steps = 0, max_steps = 0;  // COUNT: records visited by the current ray / the longest ray
-    Util util;
-    WaveQueue wq;
-    wq.init(fr.work + (size_t)(level * WORK_QUEUES) * (QPARTS * QHEAD_STRIDE), fr.counters[CTR_LEVEL_COUNT + level],
-            nthreads / 64u, gtid / 64u);
-    for (;;) {
-        unsigned long long idle = __ballot(s.cur == TRAV_DONE);
-        uint32_t nidle = (uint32_t)__popcll(idle);
-        if (wq.exhausted) {
-            if (nidle == 64u) break;
-        } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
-            uint32_t i;
-            if (wq.take(idle, s.cur == TRAV_DONE, i)) {
-                node = base + i;
-                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-                if (__float_as_uint(d4.w) != INVALID_PRIM) {
-                    init_ray(s.r, sc, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z));
-                    trav_begin<REF, OVH>(sc, s, st);
-                    if (s.cur == TRAV_DONE) {  // misses the root box
-                        fr.ray_o[node].w = 0.0f;
-                        fr.ray_d[node].w = __uint_as_float(NO_PRIM);
-                    }
-                }
-            }
-            continue;
-        }
-        // advance the active lanes until enough of them are idle again
-        const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
-        do {
-            bool active = s.cur != TRAV_DONE;
-            uint32_t before = s.nodes + s.prims;
-            wave_step<0, COUNT, REF, OVH>(sc, s, st, 0.0f, lds_top, util);
-            if (COUNT) ray_steps += s.nodes + s.prims - before;
-            if (active && s.cur == TRAV_DONE) {
-                fr.ray_o[node].w = s.any ? s.t : 0.0f;
-                fr.ray_d[node].w = __uint_as_float(s.prim);
-                if (COUNT) {
-                    max_steps = ray_steps > max_steps ? ray_steps : max_steps;
-                    ray_steps = 0;
-                }
-            }
-        } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
-    }
-    util.flush(fr.counters);
-    if (COUNT) {
-        add_visits(fr.counters, s.nodes, s.prims, CTR_VISIT_NODES_LO);
-        atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
-    }
-}
-
-template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    trace_closest_body<COUNT, REF, false>(sc, fr, level);
-}
-// The production traversal for scenes whose hits can lie outside their objects' boxes
-// (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
-template <bool COUNT>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_closest_ovh_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    trace_closest_body<COUNT, false, true>(sc, fr, level);
-}
-
 // ---------------------------------------------------------------- object.rs helpers for shading
 struct PrimView {
     float4 p0, p1, p2, p3;
@@ -957,161 +861,50 @@ __device__ __forceinline__ void object_uv(const PrimView &v, const Xform *xforms
     }
 }
 
-// ---------------------------------------------------------------- shade_forward
-// For every hit of this level: the shadow queries of world.rs:121-125 are queued per light
-// (cone pre-test of light.rs:113-116 applied here), and the bounce rays of
-// material.rs:185-203 are appended to the next level's queue.
+// ---------------------------------------------------------------- path
+// World::trace_ray (world.rs:115-131) for the batch's primary samples in ONE persistent launch.
 //
-// Queue compaction: a block takes SF_R*256 consecutive path nodes; every wave ranks its
-// lanes with ballot + popcount (shadow queues) or a shuffle prefix sum (bounce children),
-// the four wave totals are combined in LDS, and ONE atomic per queue per block reserves
-// the block's range -- a single hot counter sustains only ~90 atomics/us on MI355X, so a
-// per-wave atomic would cost more than the traversal it feeds.
-constexpr int SF_R = 4;
-constexpr int SF_Q = MAX_LIGHTS + 1;  // queues: one per light + the next level's nodes
+// A wave takes primary samples from the batch's queue and owns everything that follows from
+// them: when a closest-hit query ends, its lane -- with the hit point in hand -- writes the
+// node's record, spawns the bounce rays of the hit's material (material.rs:185-203) as child path
+// nodes, and lists one shadow query per light that wants one (ambient lights are lit without a
+// query, cone lights only inside their cone, light.rs:99-122).  Children and shadow queries go on
+// the WAVE'S OWN work stack (global memory, private to the wave: no atomics, no other wave ever
+// waits for it); idle lanes are refilled from the top of that stack first and from the batch's
+// queue of primaries when it is empty.  Entries of one kind pushed together are popped together,
+// so the lanes refilled in one go trace the shadow rays of neighbouring hit points towards the
+// SAME light (or neighbouring primaries, or the bounce rays of neighbouring hits): their first
+// node visits are the same addresses.  The stack is LIFO, so a sample's path tree is walked
+// depth-first and the stack stays small.  A shadow query's answer is OR-ed into the lit mask of
+// its node's record; the colours are resolved bottom-up by the resolve passes afterwards.  There
+// is no pass between bounce levels and no global shadow queue: a launch ends with ONE drain.
+//
+// Work entry / lane tag: x = path node, y = bits 4..0 light, bit 5 light is directional, bit 6
+// shadow query (else closest hit), bit 7 (lane tag only) a ray is in flight, bits 11..8 bounce level.
+#ifndef RTX_SHADE_MIN
+#define RTX_SHADE_MIN 32
+#endif
+constexpr uint32_t WK_LIGHT = 31u, WK_DIR = 1u << 5, WK_SHADOW = 1u << 6, WK_BUSY = 1u << 7, WK_LEVEL_SHIFT = 8;
 
-__global__ void __launch_bounds__(BLOCK) shade_forward_kernel(DeviceScene sc, Frame fr, uint32_t level,
-                                                              uint32_t max_levels) {
-    __shared__ uint32_t s_tot[BLOCK / 64][SF_Q];  // per-wave totals, then per-wave offsets
-    __shared__ uint32_t s_base[SF_Q];
-    const uint32_t base = level_base(fr.counters, level);
-    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
-    const uint32_t next_base = base + count;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t nl = sc.n_lights;
-    for (uint32_t i0 = blockIdx.x * (BLOCK * SF_R); i0 < count; i0 += gridDim.x * (BLOCK * SF_R)) {
-        // ---- phase 1: what does every node need?
-        uint32_t want[SF_R], nb[SF_R], lit[SF_R];
-#pragma unroll
-        for (int r = 0; r < SF_R; r++) {
-            uint32_t i = i0 + r * BLOCK + threadIdx.x;
-            want[r] = 0;
-            nb[r] = 0;
-            lit[r] = 0;
-            if (i < count) {
-                uint32_t node = base + i;
-                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-                uint32_t prim = __float_as_uint(d4.w);
-                if (prim < INVALID_PRIM) {
-                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);  // world.rs:120
-                    for (uint32_t l = 0; l < nl; l++) {
-                        const LightRec &L = sc.lights[l];
-                        if (L.type == LIGHT_AMBIENT) lit[r] |= 1u << l;
-                        else if (L.type == LIGHT_CONE) {
-                            F3 ld = p - f3(L.pos[0], L.pos[1], L.pos[2]);
-                            if (!(angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), ld) > L.angle_deg * DEG_TO_RAD))
-                                want[r] |= 1u << l;
-                        } else want[r] |= 1u << l;
-                    }
-                    if (level + 1 < max_levels) {
-                        uint32_t meta = sc.prims[prim].meta;
-                        nb[r] = sc.mats[meta >> 16].n_bounce;
-                    }
-                }
-            }
-        }
-        // ---- wave totals -> LDS -> one atomic per queue per block
-        for (uint32_t l = 0; l < nl; l++) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int r = 0; r < SF_R; r++) tot += (uint32_t)__popcll(__ballot((want[r] >> l) & 1u));
-            if (lane == 0) s_tot[wave][l] = tot;
-        }
-        uint32_t child_off[SF_R];
-        {
-            uint32_t run = 0;
-#pragma unroll
-            for (int r = 0; r < SF_R; r++) {
-                uint32_t incl = nb[r];
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    uint32_t up = __shfl_up(incl, d, 64);
-                    if (lane >= (uint32_t)d) incl += up;
-                }
-                child_off[r] = run + incl - nb[r];
-                run += __shfl(incl, 63, 64);
-            }
-            if (lane == 0) s_tot[wave][MAX_LIGHTS] = run;
-        }
-        __syncthreads();
-        if (threadIdx.x < (uint32_t)SF_Q) {
-            uint32_t q = threadIdx.x;
-            bool used = q < nl || q == (uint32_t)MAX_LIGHTS;
-            uint32_t sum = 0;
-            if (used) {
-                for (int w = 0; w < BLOCK / 64; w++) {
-                    uint32_t t = s_tot[w][q];
-                    s_tot[w][q] = sum;
-                    sum += t;
-                }
-            }
-            uint32_t b = 0;
-            if (used && sum) {
-                uint32_t *ctr = q == (uint32_t)MAX_LIGHTS ? fr.counters + CTR_LEVEL_COUNT + level + 1
-                                                          : fr.counters + CTR_SHADOW_COUNT + level * MAX_LIGHTS + q;
-                b = atomicAdd(ctr, sum);
-            }
-            s_base[q] = b;
-        }
-        __syncthreads();
-        // ---- phase 2: write the queue entries, the bounce rays and the node links
-        for (uint32_t l = 0; l < nl; l++) {
-            uint32_t run = s_base[l] + s_tot[wave][l];
-#pragma unroll
-            for (int r = 0; r < SF_R; r++) {
-                bool mine = (want[r] >> l) & 1u;
-                unsigned long long mask = __ballot(mine);
-                if (mine) {
-                    uint32_t slot = run + (uint32_t)__popcll(mask & lt_mask);
-                    if (slot < fr.q_cap) fr.shadow_q[((size_t)level * nl + l) * fr.q_cap + slot] = base + i0 + r * BLOCK + threadIdx.x;
-                    else fr.counters[CTR_OVERFLOW] = 1;
-                }
-                run += (uint32_t)__popcll(mask);
-            }
-        }
-        const uint32_t child_base = next_base + s_base[MAX_LIGHTS] + s_tot[wave][MAX_LIGHTS];
-#pragma unroll
-        for (int r = 0; r < SF_R; r++) {
-            uint32_t i = i0 + r * BLOCK + threadIdx.x;
-            if (i >= count) continue;
-            uint32_t node = base + i;
-            uint32_t child = NO_PRIM;
-            if (nb[r]) {
-                uint32_t first = child_base + child_off[r];
-                if (first + nb[r] <= fr.node_cap) {
-                    child = first;
-                    float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-                    F3 d = f3(d4.x, d4.y, d4.z);
-                    F3 p = f3(o4.x, o4.y, o4.z) + o4.w * d;
-                    PrimView pv = load_prim(sc.prims + __float_as_uint(d4.w));
-                    MaterialRec m = sc.mats[pv.mat];
-                    F3 normal = object_normal(pv, sc.xforms, p);
-                    for (uint32_t k = 0; k < m.prog_count; k++) {
-                        const MatInstr &ins = sc.prog[m.prog_first + k];
-                        if (ins.op != OP_REFLECT && ins.op != OP_REFRACT) continue;
-                        F3 nd = (ins.op == OP_REFLECT) ? reflect(d, normal) : refract(d, normal, ins.p0);
-                        // Ray::new(p, nd).offset(1e-4) (material.rs:189-191, ray.rs:43-46)
-                        F3 rd = normalize(nd);
-                        F3 ro = p + 1e-4f * rd;
-                        rd = normalize(rd);
-                        uint32_t cn = child + ins.arg;
-                        fr.ray_o[cn] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-                        fr.ray_d[cn] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(NO_PRIM));
-                    }
-                } else {
-                    fr.counters[CTR_OVERFLOW] = 1;
-                }
-            }
-            fr.link[node] = make_uint2(lit[r], child);
-        }
-        __syncthreads();  // s_tot / s_base are reused by the next iteration
+// light.rs:113-116: is `point` outside the cone?  The reference compares atan2(|a x b|, a . b)
+// with the cut-off; the signed squared cosine settles every point that is not within 1e-4 of the
+// cut-off (both sides of the comparison carry a few 1e-7 of rounding), the rest -- behind one
+// wave-uniform branch -- runs the reference's expression.
+__device__ __forceinline__ bool outside_cone(const LightRec &L, F3 point) {
+    const F3 a = f3(L.dir[0], L.dir[1], L.dir[2]);
+    const F3 b = point - f3(L.pos[0], L.pos[1], L.pos[2]);
+    const float dt = dot(a, b), l2 = dot(a, a) * dot(b, b);
+    const float q = dt * fabsf(dt), cc = (L.cos_cut * fabsf(L.cos_cut)) * l2, m = 1e-4f * l2;
+    bool outside = q < cc - m;
+    const bool marginal = !outside && !(q > cc + m);
+    if (__ballot(marginal) != 0ull) {
+        if (marginal) outside = angle_rad(a, b) > L.angle_deg * DEG_TO_RAD;
     }
+    return outside;
 }
 
-// ---------------------------------------------------------------- trace_shadow
-template <bool COUNT, bool REF, bool OVH>
-__device__ __forceinline__ void trace_shadow_body(const DeviceScene &sc, const Frame &fr, uint32_t level) {
+template <bool COUNT, bool REF, bool OVH, bool SHADE>
+__device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
@@ -1122,8 +915,11 @@ __device__ __forceinline__ void trace_shadow_body(const DeviceScene &sc, const F
         }
         __syncthreads();
     }
+    const uint32_t n0 = fr.counters[CTR_LEVEL_COUNT];
     const uint32_t nthreads = gridDim.x * TBLOCK;
     const uint32_t gtid = blockIdx.x * TBLOCK + threadIdx.x;
+    const uint32_t lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     Stack st;
     st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
     st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
@@ -1132,93 +928,261 @@ __device__ __forceinline__ void trace_shadow_body(const DeviceScene &sc, const F
     Trav s;
     s.cur = TRAV_DONE;
     s.nodes = s.prims = 0;
-    uint32_t node = 0;
-    uint32_t ray_steps = 0, max_steps = 0;
+    s.t = 0.0f;
+    s.prim = NO_PRIM;
+    s.any = s.occluded = false;
+    uint32_t node = NO_PRIM, tag = 0;
+    // the wave's work stack and its run of pool nodes (wave-uniform)
+    uint2 *const wk = fr.wstack + (size_t)(gtid / 64u) * (fr.wstack_cap + (uint32_t)SHADE_LIST);
+    uint2 *const wsh = wk + fr.wstack_cap;              // hits waiting for the shading pass: (node, level)
+    const uint32_t wk_cap = fr.wstack_cap;
+    uint32_t top = 0, shn = 0, run_next = 0, run_end = 0;
+    uint32_t n_shadow = 0, n_bounce = 0;
+    // entries that one closest-hit query can push when it ends (admission of new primaries)
+    uint32_t per_hit = sc.max_bounce;
+    for (uint32_t l = 0; l < sc.n_lights; l++) per_hit += sc.lights[l].type != LIGHT_AMBIENT ? 1u : 0u;
+    uint32_t vis_cn = 0, vis_cp = 0, vis_sn = 0, vis_sp = 0, max_steps = 0;  // COUNT
     Util util;
-    float dist = 0.0f;
-    // The lights' queues of this level form ONE index space (light 0's entries, then light
-    // 1's, ...): a wave drains -- runs its last, longest rays with most lanes idle -- once per
-    // launch instead of once per light.  The light of a lane's ray is per-lane state.
-    uint32_t light = 0;  // bits 7..0 light index, bit 8 directional
-    uint32_t total = 0;
-    for (uint32_t l = 0; l < sc.n_lights; l++) {
-        uint32_t c = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
-        total += c > fr.q_cap ? fr.q_cap : c;
-    }
     WaveQueue wq;
-    wq.init(fr.work + (size_t)(level * WORK_QUEUES + 1) * (QPARTS * QHEAD_STRIDE), total, nthreads / 64u, gtid / 64u);
+    wq.init(fr.work, n0, nthreads / 64u, gtid / 64u);
     for (;;) {
-        unsigned long long idle = __ballot(s.cur == TRAV_DONE);
-        uint32_t nidle = (uint32_t)__popcll(idle);
+        const bool idle = s.cur == TRAV_DONE;
+        const bool fin = idle && (tag & WK_BUSY);
+        const unsigned long long idlem = __ballot(idle), finm = __ballot(fin);
+        const uint32_t nidle = (uint32_t)__popcll(idlem), nfin = (uint32_t)__popcll(finm), nact = 64u - nidle;
+        const uint32_t avail = top + shn + (wq.exhausted ? 0u : 64u);
+        if (nact == 0u && nfin == 0u && avail == 0u) break;
+        // lanes between rays are handled together once enough of them wait: a quarter of the
+        // wave (of what is left of it once the queue of primaries is dry)
+        const uint32_t serve = nidle < avail ? nidle : avail;
+        const uint32_t pending = nfin > serve ? nfin : serve;
+        uint32_t thr = (uint32_t)RTX_REFILL_MIN;
         if (wq.exhausted) {
-            if (nidle == 64u) break;
-        } else if (nidle >= (uint32_t)RTX_REFILL_MIN) {
-            uint32_t i;
-            if (wq.take(idle, s.cur == TRAV_DONE, i)) {
-                uint32_t l = 0;
-                for (; l + 1u < sc.n_lights; l++) {  // ambient lights have empty queues
-                    uint32_t c = fr.counters[CTR_SHADOW_COUNT + level * MAX_LIGHTS + l];
-                    c = c > fr.q_cap ? fr.q_cap : c;
-                    if (i < c) break;
-                    i -= c;
-                }
-                const LightRec &L = sc.lights[l];
-                const bool directional = L.type == LIGHT_DIRECTIONAL;
-                light = l | (directional ? 0x100u : 0u);
-                node = fr.shadow_q[((size_t)level * sc.n_lights + l) * fr.q_cap + i];
-                float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-                F3 p = f3(o4.x, o4.y, o4.z) + o4.w * f3(d4.x, d4.y, d4.z);
-                if (directional) {
-                    // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
-                    F3 rd = normalize(-f3(L.dir[0], L.dir[1], L.dir[2]));
-                    F3 ro = p + 1e-4f * rd;
-                    rd = normalize(rd);
-                    dist = INFINITY;  // any hit at all blocks a directional light
-                    init_ray(s.r, sc, ro, rd);
-                } else {
-                    // Light::in_shadow (light.rs:81-97)
-                    const F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
-                    F3 rd = normalize(p - lpos);
-                    dist = magnitude(lpos - p);
-                    init_ray(s.r, sc, lpos, rd);
-                }
-                trav_begin<REF, OVH>(sc, s, st);
-                // a ray that misses the root box hits nothing: directional light reaches,
-                // point / cone light does not (light.rs:93-96)
-                if (s.cur == TRAV_DONE && directional) atomicOr(&fr.link[node].x, 1u << l);
-            }
+            const uint32_t live = nact + pending;
+            thr = live >= 4u * (uint32_t)RTX_REFILL_MIN ? (uint32_t)RTX_REFILL_MIN : (live >= 8u ? live / 4u : 1u);
+        }
+        if (pending < thr && nact != 0u) {
+            const uint32_t stop_at = nidle + (thr - pending) < 64u ? nidle + (thr - pending) : 64u;
+            do {
+                wave_step<COUNT, REF, OVH>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
+            } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
             continue;
         }
-        const uint32_t stop_at = wq.exhausted ? 64u : (uint32_t)RTX_REFILL_MIN;
-        do {
-            bool active = s.cur != TRAV_DONE;
-            uint32_t before = s.nodes + s.prims;
-            wave_step<1, COUNT, REF, OVH>(sc, s, st, dist, lds_top, util);
-            if (COUNT) ray_steps += s.nodes + s.prims - before;
-            if (active && s.cur == TRAV_DONE) {
-                bool reaches = (light & 0x100u) ? !s.any : (s.any && !s.occluded);
-                if (reaches) atomicOr(&fr.link[node].x, 1u << (light & 0xFFu));
+        // ---- the rays that have just finished
+        if (nfin != 0u) {
+            if (SHADE && fin && (tag & WK_SHADOW)) {
+                // light.rs:93-96 / 111: point and cone lights reach iff something was hit and nothing
+                // in front of the point; a directional light reaches iff nothing was hit at all
+                const bool reaches = (tag & WK_DIR) ? !s.any : (s.any && !s.occluded);
+                if (reaches) atomicOr(&fr.link[node].x, 1u << (tag & WK_LIGHT));
                 if (COUNT) {
-                    max_steps = ray_steps > max_steps ? ray_steps : max_steps;
-                    ray_steps = 0;
+                    vis_sn += s.nodes;
+                    vis_sp += s.prims;
+                    max_steps = max(max_steps, s.nodes + s.prims);
+                    s.nodes = s.prims = 0;
                 }
             }
-        } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
+            const bool finc = fin && !(tag & WK_SHADOW);
+            if (finc) {
+                fr.ray_o[node].w = s.any ? s.t : 0.0f;
+                fr.ray_d[node].w = __uint_as_float(s.prim);
+                if (COUNT) {
+                    vis_cn += s.nodes;
+                    vis_cp += s.prims;
+                    max_steps = max(max_steps, s.nodes + s.prims);
+                    s.nodes = s.prims = 0;
+                }
+                // a miss is the background (world.rs:127-130): nothing to shade
+                if (SHADE && !s.any) fr.link[node] = make_uint2((tag >> WK_LEVEL_SHIFT) << LINK_LEVEL_SHIFT, NO_PRIM);
+            }
+            if constexpr (SHADE) {
+                // hits wait in the wave's shading list until enough of them make a full-width pass
+                const bool hitc = finc && s.any;
+                const unsigned long long hm = __ballot(hitc);
+                if (hitc) wsh[shn + (uint32_t)__popcll(hm & lt_mask)] = make_uint2(node, tag >> WK_LEVEL_SHIFT);
+                shn += (uint32_t)__popcll(hm);
+            }
+            if (fin) tag &= ~WK_BUSY;
+        }
+        // ---- shading pass over the listed hits (world.rs:120-125, material.rs:185-203): which lights
+        // want a shadow query, the bounce children; run by the idle lanes once SHADE_MIN hits wait
+        if constexpr (SHADE) {
+            if (shn >= (uint32_t)RTX_SHADE_MIN || shn > (uint32_t)SHADE_LIST - 64u || (shn != 0u && wq.exhausted && top < nidle)) {
+                const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
+                const uint32_t n_sh = nidle < shn ? nidle : shn;
+                const bool mine = idle && rank < n_sh;
+                uint32_t hnode = 0, level = 0, hprim = 0, lit0 = 0, want = 0, nb = 0;
+                F3 p = f3(0.f, 0.f, 0.f), d = p;
+                if (mine) {
+                    const uint2 e = wsh[shn - n_sh + rank];
+                    hnode = e.x;
+                    level = e.y;
+                    const float4 o4 = fr.ray_o[hnode], d4 = fr.ray_d[hnode];
+                    d = f3(d4.x, d4.y, d4.z);
+                    p = f3(o4.x, o4.y, o4.z) + o4.w * d;  // world.rs:120
+                    hprim = __float_as_uint(d4.w);
+                    if (level + 1u < max_levels) nb = sc.mats[sc.prims[hprim].meta >> 16].n_bounce;
+                }
+                shn -= n_sh;
+                for (uint32_t l = 0; l < sc.n_lights; l++) {
+                    const LightRec &L = sc.lights[l];
+                    if (L.type == LIGHT_AMBIENT) lit0 |= 1u << l;
+                    else if (L.type != LIGHT_CONE || !outside_cone(L, p)) want |= 1u << l;
+                }
+                if (!mine) lit0 = want = 0;
+                // bounce children: path nodes from this wave's run of the pool
+                uint32_t first = NO_PRIM;
+                const unsigned long long b0 = __ballot(nb & 1u), b1 = __ballot(nb & 2u), b2 = __ballot(nb & 4u);
+                if ((b0 | b1 | b2) != 0ull) {
+                    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+                    const uint32_t before = (uint32_t)__popcll(b0 & lt_mask) + 2u * (uint32_t)__popcll(b1 & lt_mask) +
+                                            4u * (uint32_t)__popcll(b2 & lt_mask);
+                    if (run_next + total > run_end) {
+                        // the rest of the old run becomes holes, a new run is reserved with ONE atomic
+                        for (uint32_t h = run_next + lane; h < run_end; h += 64u)
+                            fr.link[n0 + h] = make_uint2(LINK_LEVEL_HOLE << LINK_LEVEL_SHIFT, NO_PRIM);
+                        const uint32_t wanted = total > (uint32_t)POOL_RUN ? total : (uint32_t)POOL_RUN;
+                        run_next = wave_fetch(fr.counters + CTR_POOL, wanted);
+                        run_end = run_next + wanted;
+                        if ((unsigned long long)n0 + run_end > fr.node_cap) run_end = run_next;  // sizing error
+                    }
+                    if (run_next != run_end && top + total <= wk_cap) {
+                        if (nb) {
+                            first = n0 + run_next + before;
+                            const PrimView pv = load_prim(sc.prims + hprim);
+                            const MaterialRec m = sc.mats[pv.mat];
+                            const F3 normal = object_normal(pv, sc.xforms, p);
+                            for (uint32_t k = 0; k < m.prog_count; k++) {
+                                const MatInstr &ins = sc.prog[m.prog_first + k];
+                                if (ins.op != OP_REFLECT && ins.op != OP_REFRACT) continue;
+                                F3 nd = (ins.op == OP_REFLECT) ? reflect(d, normal) : refract(d, normal, ins.p0);
+                                // Ray::new(p, nd).offset(1e-4) (material.rs:189-191, ray.rs:43-46)
+                                F3 rd = normalize(nd);
+                                F3 ro = p + 1e-4f * rd;
+                                rd = normalize(rd);
+                                const uint32_t cn = first + ins.arg;
+                                fr.ray_o[cn] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                                fr.ray_d[cn] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(NO_PRIM));
+                                wk[top + before + ins.arg] = make_uint2(cn, (level + 1u) << WK_LEVEL_SHIFT);
+                            }
+                        }
+                        run_next += total;
+                        top += total;
+                        n_bounce += total;
+                    } else {  // reported; the children are dropped
+                        if (lane == 0) fr.counters[CTR_OVERFLOW] = 1;
+                        nb = 0;
+                    }
+                }
+                if (mine) fr.link[hnode] = make_uint2(lit0 | (level << LINK_LEVEL_SHIFT) | (nb << LINK_NB_SHIFT), first);
+                // shadow queries, light by light, on top of the children: they are traced next
+                for (uint32_t l = 0; l < sc.n_lights; l++) {
+                    const bool wl = (want >> l) & 1u;
+                    const unsigned long long m = __ballot(wl);
+                    if (m == 0ull) continue;
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    if (top + cnt > wk_cap) {
+                        if (lane == 0) fr.counters[CTR_OVERFLOW] = 1;
+                        continue;
+                    }
+                    if (wl)
+                        wk[top + (uint32_t)__popcll(m & lt_mask)] =
+                            make_uint2(hnode, l | (sc.lights[l].type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
+                                                  (level << WK_LEVEL_SHIFT));
+                    top += cnt;
+                    n_shadow += cnt;
+                }
+            }
+        }
+        // ---- work for the idle lanes: the top of the wave's stack first, then new primaries
+        {
+            const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
+            const uint32_t n_pop = nidle < top ? nidle : top;
+            bool got = false;
+            if (idle && rank < n_pop) {
+                const uint2 e = wk[top - n_pop + rank];
+                node = e.x;
+                tag = e.y | WK_BUSY;
+                got = true;
+            }
+            top -= n_pop;
+            if (nidle > n_pop && !wq.exhausted) {
+                // every closest-hit query in flight and every listed hit can still push per_hit entries
+                uint32_t n_new = nidle - n_pop;
+                if (SHADE) {
+                    const uint32_t inflight = (uint32_t)__popcll(__ballot((tag & (WK_BUSY | WK_SHADOW)) == WK_BUSY));
+                    const uint32_t used = top + (inflight + shn) * per_hit, half = wk_cap / 2u;
+                    const uint32_t room = used < half ? (half - used) / (per_hit ? per_hit : 1u) : 0u;
+                    n_new = n_new < room ? n_new : room;
+                }
+                const bool wants = idle && rank >= n_pop && rank < n_pop + n_new;
+                const unsigned long long wmask = __ballot(wants);
+                if (wmask != 0ull) {
+                    uint32_t i = 0;
+                    if (wq.take(wmask, wants, i)) {
+                        node = i;
+                        tag = WK_BUSY;  // closest-hit query, level 0
+                        got = true;
+                    }
+                }
+            }
+            // ---- begin the new rays
+            if (got) {
+                const float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                F3 ro = f3(o4.x, o4.y, o4.z), rd = f3(d4.x, d4.y, d4.z);
+                float dist = INFINITY;  // closest hit: nothing found yet; directional light: any hit at all blocks
+                if (tag & WK_SHADOW) {
+                    const F3 p = ro + o4.w * rd;  // world.rs:120
+                    const LightRec &L = sc.lights[tag & WK_LIGHT];
+                    if (tag & WK_DIR) {
+                        // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
+                        rd = normalize(-f3(L.dir[0], L.dir[1], L.dir[2]));
+                        ro = p + 1e-4f * rd;
+                        rd = normalize(rd);
+                    } else {
+                        // Light::in_shadow (light.rs:81-97)
+                        ro = f3(L.pos[0], L.pos[1], L.pos[2]);
+                        rd = normalize(p - ro);
+                        dist = magnitude(ro - p);
+                    }
+                }
+                if (!(tag & WK_SHADOW) && __float_as_uint(d4.w) == INVALID_PRIM) {  // pixel slot outside the image (padded tile)
+                    if (SHADE) fr.link[node] = make_uint2(0u, NO_PRIM);
+                    tag = 0;
+                } else {
+                    init_ray(s.r, sc, ro, rd);
+                    s.t = dist;
+                    trav_begin<REF, OVH>(sc, s, st);  // (a ray that misses the root box is done at once)
+                }
+            }
+        }
     }
-    util.flush(fr.counters + 10);
+    // what is left of the wave's last run of pool nodes
+    if constexpr (SHADE) {
+        for (uint32_t h = run_next + lane; h < run_end; h += 64u)
+            fr.link[n0 + h] = make_uint2(LINK_LEVEL_HOLE << LINK_LEVEL_SHIFT, NO_PRIM);
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(fr.counters + CTR_BOUNCE_LO), (unsigned long long)n_bounce);
+            atomicAdd(reinterpret_cast<unsigned long long *>(fr.counters + CTR_SHADOW_LO), (unsigned long long)n_shadow);
+        }
+    }
+    util.flush(fr.counters);
     if (COUNT) {
-        add_visits(fr.counters, s.nodes, s.prims, CTR_SVISIT_NODES_LO);
+        add_visits(fr.counters, vis_cn, vis_cp, CTR_VISIT_NODES_LO);
+        add_visits(fr.counters, vis_sn, vis_sp, CTR_SVISIT_NODES_LO);
         atomicMax(fr.counters + CTR_MAX_STEPS, max_steps);
     }
 }
 
-template <bool COUNT, bool REF>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    trace_shadow_body<COUNT, REF, false>(sc, fr, level);
+template <bool COUNT, bool REF, bool SHADE>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
+    path_body<COUNT, REF, false, SHADE>(sc, fr, max_levels);
 }
-template <bool COUNT>
-__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) trace_shadow_ovh_kernel(DeviceScene sc, Frame fr, uint32_t level) {
-    trace_shadow_body<COUNT, false, true>(sc, fr, level);
+// The production traversal for scenes whose hits can lie outside their objects' boxes
+// (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
+template <bool COUNT, bool SHADE>
+__global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_ovh_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
+    path_body<COUNT, false, true, SHADE>(sc, fr, max_levels);
 }
 
 // ---------------------------------------------------------------- resolve
@@ -1261,17 +1225,19 @@ __device__ __forceinline__ F3 texture_sample(const DeviceScene &sc, const Materi
     return crgb(0.5f, 0.5f, 0.5f);
 }
 
-__global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level, uint32_t phase) {
-    const uint32_t base = level_base(fr.counters, level);
-    const uint32_t count = fr.counters[CTR_LEVEL_COUNT + level];
+// Level 0 = the batch's primary samples, nodes [0, n0); the nodes of a deeper level are those
+// pool nodes [n0, n0 + pool) whose link carries that level (runs of the pool belong to waves, so
+// the levels are interleaved; unused slots of a run are marked as holes).
+__global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level) {
+    const uint32_t n0 = fr.counters[CTR_LEVEL_COUNT];
+    const uint32_t base = level == 0u ? 0u : n0;
+    const uint32_t count = level == 0u ? n0 : min(fr.counters[CTR_POOL], fr.node_cap - n0);
     const uint32_t nthreads = gridDim.x * BLOCK;
     const F3 bg = f3(sc.background[0], sc.background[1], sc.background[2]);
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += nthreads) {
         uint32_t node = base + i;
-        // shade_forward left a link for every node of the level (misses: no child): the phase
-        // filter needs only those 8 bytes, not the ray
         const uint2 lk = fr.link[node];
-        if (phase != RESOLVE_ALL && (phase == RESOLVE_PARENTS) != (lk.y != NO_PRIM)) continue;
+        if (level != 0u && ((lk.x >> LINK_LEVEL_SHIFT) & 15u) != level) continue;
         float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
         uint32_t prim = __float_as_uint(d4.w);
         F3 res;
@@ -1423,39 +1389,27 @@ void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, 
 void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc) {
     hipLaunchKernelGGL(load_rays_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, org_dir, n);
 }
-void launch_trace_closest(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
+void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc) {
     dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
-    if (lc.reference_traversal) {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_closest_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
+#define RTX_LAUNCH_PATH(K) hipLaunchKernelGGL(K, g, b, 0, lc.stream, sc, fr, max_levels)
+    if (!shade) {  // closest hits of the primaries only (no visit counters on this path)
+        if (lc.reference_traversal) RTX_LAUNCH_PATH((path_kernel<false, true, false>));
+        else if (sc.overhang != 0.0f) RTX_LAUNCH_PATH((path_ovh_kernel<false, false>));
+        else RTX_LAUNCH_PATH((path_kernel<false, false, false>));
+    } else if (lc.reference_traversal) {
+        if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, true, true>));
+        else RTX_LAUNCH_PATH((path_kernel<false, true, true>));
     } else if (sc.overhang != 0.0f) {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_ovh_kernel<true>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_closest_ovh_kernel<false>), g, b, 0, lc.stream, sc, fr, level);
+        if (lc.count_visits) RTX_LAUNCH_PATH((path_ovh_kernel<true, true>));
+        else RTX_LAUNCH_PATH((path_ovh_kernel<false, true>));
     } else {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_closest_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
+        if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, false, true>));
+        else RTX_LAUNCH_PATH((path_kernel<false, false, true>));
     }
+#undef RTX_LAUNCH_PATH
 }
-void launch_trace_shadow(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
-    dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
-    if (lc.reference_traversal) {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, true>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_shadow_kernel<false, true>), g, b, 0, lc.stream, sc, fr, level);
-    } else if (sc.overhang != 0.0f) {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_ovh_kernel<true>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_shadow_ovh_kernel<false>), g, b, 0, lc.stream, sc, fr, level);
-    } else {
-        if (lc.count_visits) hipLaunchKernelGGL((trace_shadow_kernel<true, false>), g, b, 0, lc.stream, sc, fr, level);
-        else hipLaunchKernelGGL((trace_shadow_kernel<false, false>), g, b, 0, lc.stream, sc, fr, level);
-    }
-}
-void launch_shade_forward(const DeviceScene &sc, const Frame &fr, uint32_t level, uint32_t max_levels,
-                          const LaunchCfg &lc) {
-    hipLaunchKernelGGL(shade_forward_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level,
-                       max_levels);
-}
-void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, ResolvePhase phase, const LaunchCfg &lc) {
-    hipLaunchKernelGGL(resolve_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level, (uint32_t)phase);
+void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {
+    hipLaunchKernelGGL(resolve_kernel, dim3(lc.persistent_blocks), dim3(BLOCK), 0, lc.stream, sc, fr, level);
 }
 void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, float4 *sum, uint8_t *tiles_rgb8,
                        float *tiles_f32, const LaunchCfg &lc) {
@@ -1475,7 +1429,7 @@ int query_persistent_blocks(int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_closest_kernel<false, false>, TBLOCK, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel<false, false, true>, TBLOCK, 0) !=
             hipSuccess ||
         per_cu < 1)
         per_cu = 4 * BLOCK / TBLOCK;

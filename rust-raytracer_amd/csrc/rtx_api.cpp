@@ -25,17 +25,13 @@ double now_s() {
 }
 }  // namespace
 
-// One in-flight batch: its wavefront buffers and the two streams its kernels run on.
+// One in-flight batch: its wavefront buffers and the stream its kernels run on.
 struct Pipe {
     Frame fr{};
     std::vector<void *> allocs;
-    uint64_t node_cap = 0, q_cap = 0;
-    uint32_t lights = 0, levels = 0, spill_entries = 0;
-    bool side_spills = false;
+    uint64_t n0_cap = 0, node_cap = 0;
+    uint32_t spill_entries = 0, wstack_cap = 0;
     hipStream_t main = nullptr;
-    std::vector<hipStream_t> sides;   // trace_shadow(k) runs on sides[k % n], beside trace_closest(k+1)
-    std::vector<uint32_t *> spill_side;  // traversal-stack overflow of the kernels on each side stream
-    std::vector<hipEvent_t> order;    // ordering events between the two streams (no timing)
 };
 
 struct rtx_ctx {
@@ -53,6 +49,7 @@ struct rtx_ctx {
     std::vector<uint32_t> leaf_order, preorder_sizes;
     rtx_bvh_info info{};
     uint32_t max_bounce = 0;
+    uint32_t per_hit = 0;             // work entries one closest hit can push: bounce children + non-ambient lights
     // per-render state
     float4 *sum = nullptr;
     uint8_t *tiles = nullptr;
@@ -66,7 +63,9 @@ struct rtx_ctx {
     int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
     uint8_t *scratch = nullptr;       // this device's copy of the static scratch array (rtx_render_device_noalloc)
-    uint64_t overlap_below = ~0ull;  // renders with fewer primary samples run their kernels concurrently (RTX_CONCURRENT=0: none)
+    uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
+    uint32_t pending_batches = 0;     // batches of the last asynchronous render whose overflow flags nobody has looked at
+    bool use_pipes = true;            // batches of a render alternate between the pipes (RTX_CONCURRENT=0: one pipe)
 };
 
 namespace {
@@ -152,18 +151,27 @@ uint64_t geo_sum(uint32_t K, uint32_t levels) {
     }
     return std::max<uint64_t>(s, 1);
 }
-uint64_t geo_last(uint32_t K, uint32_t levels) {
-    uint64_t g = 1;
-    for (uint32_t k = 1; k < levels; k++) g *= K;
-    if (levels > 1 && K == 0) return 1;
-    return std::max<uint64_t>(g, 1);
+
+// Path nodes that `n0` primary samples traced `levels` deep can need: the samples themselves plus a
+// pool for their bounce children -- at most K per hit -- which the waves of the path kernel take in
+// runs of POOL_RUN (the slack: every wave can strand one run).
+uint64_t node_capacity(const rtx_ctx *c, uint64_t n0, uint32_t levels, size_t threads) {
+    const uint64_t children = n0 * (geo_sum(c->max_bounce, levels) - 1);
+    return n0 + (children ? children + (uint64_t)(threads / 64) * POOL_RUN : 0);
 }
 
-// Lays the wavefront buffers of one batch (`n0` primary samples traced `levels` deep, `threads`
-// persistent threads, `npix` pixel sums) out in [base, ...) and returns the bytes used; with
+// Entries of a wave's work stack (path kernel): its depth-first walk keeps at most the untraced
+// children and shadow queries of the <= 64 paths it has in flight, level by level; new primaries
+// are admitted only while the stack is under half of this.
+uint32_t wstack_capacity(const rtx_ctx *c, uint32_t levels) {
+    return std::max<uint32_t>(1024, 64u * std::max(c->per_hit, 1u) * (levels + 2));
+}
+
+// Lays the wavefront buffers of one batch (`n0` primary samples, `node_cap` path nodes, `threads`
+// persistent threads, `npix` pixel sums or 0) out in [base, ...) and returns the bytes used; with
 // base == nullptr it only measures.  Used for the static scratch of rtx_render_device_noalloc.
-size_t layout_frame(uint8_t *base, uint64_t node_cap, uint64_t q_cap, uint32_t levels, uint32_t nl, size_t threads,
-                    uint32_t spill_entries, uint64_t npix, Frame &fr, float4 **sum) {
+size_t layout_frame(uint8_t *base, uint64_t n0, uint64_t node_cap, size_t threads, uint32_t spill_entries,
+                    uint32_t wstack_cap, uint64_t npix, Frame &fr, float4 **sum) {
     size_t off = 0;
     auto take = [&](size_t bytes) -> uint8_t * {
         uint8_t *p = base ? base + off : nullptr;
@@ -174,41 +182,37 @@ size_t layout_frame(uint8_t *base, uint64_t node_cap, uint64_t q_cap, uint32_t l
     fr.ray_d = (float4 *)take(node_cap * sizeof(float4));
     fr.link = (uint2 *)take(node_cap * sizeof(uint2));
     fr.color = (float4 *)take(node_cap * sizeof(float4));
-    fr.shadow_q = (uint32_t *)take((size_t)levels * nl * q_cap * sizeof(uint32_t));
+    fr.wstack = (uint2 *)take((threads / 64) * (wstack_cap + SHADE_LIST) * sizeof(uint2));
     fr.counters = (uint32_t *)take(CTR_WORDS * sizeof(uint32_t));
     fr.work = (uint32_t *)take(WORK_WORDS * sizeof(uint32_t));
     fr.spill = (uint32_t *)take(threads * spill_entries * sizeof(uint32_t) * 2);
-    *sum = (float4 *)take(npix * sizeof(float4));
+    if (sum) *sum = (float4 *)take(npix * sizeof(float4));
     fr.node_cap = (uint32_t)node_cap;
-    fr.q_cap = (uint32_t)q_cap;
+    fr.wstack_cap = wstack_cap;
+    (void)n0;
     return off;
 }
 
-// Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep
-// (`side_spills`: also the stack-spill buffers of the side streams, for the concurrent schedule).
-int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels, bool side_spills = false) {
-    uint32_t K = c->max_bounce;
-    uint64_t node_cap = n0 * geo_sum(K, levels);
-    uint64_t q_cap = n0 * geo_last(K, levels);
-    uint32_t nl = std::max<uint32_t>(c->ds.n_lights, 1);
+// Makes sure the pipe's wavefront buffers hold `n0` primary samples traced `levels` deep.
+int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
+    const size_t threads = (size_t)c->persistent_blocks * 256;
+    const uint64_t node_cap = node_capacity(c, n0, levels, threads);
     if (node_cap >= 0xFFFFFF00ull) {
         c->err = "batch exceeds 2^32 path nodes";
         return RTX_ERR_CAPACITY;
     }
-    if (pp.fr.ray_o && node_cap <= pp.node_cap && q_cap <= pp.q_cap && nl <= pp.lights && levels <= pp.levels &&
-        c->spill_entries <= pp.spill_entries && (!side_spills || pp.side_spills)) {
+    // (a frame laid out for more primaries keeps its pool: the pool begins at the batch's own n0)
+    const uint32_t wcap = wstack_capacity(c, levels);
+    if (pp.fr.ray_o && node_cap <= pp.node_cap && node_cap - n0 <= pp.node_cap - pp.n0_cap && c->spill_entries <= pp.spill_entries &&
+        wcap <= pp.wstack_cap) {
         pp.fr.node_cap = (uint32_t)pp.node_cap;
-        pp.fr.q_cap = (uint32_t)pp.q_cap;
+        pp.fr.wstack_cap = pp.wstack_cap;
         return RTX_OK;
     }
-    side_spills = side_spills || pp.side_spills;
     HIP_TRY(c, hipStreamSynchronize(pp.main));
-    for (auto sd : pp.sides) HIP_TRY(c, hipStreamSynchronize(sd));
     free_all(pp.allocs);
     pp.fr = Frame{};
-    pp.spill_side.assign(pp.sides.size(), nullptr);
-    pp.node_cap = pp.q_cap = 0;
-    pp.side_spills = false;
+    pp.node_cap = pp.n0_cap = 0;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
         if (e == hipSuccess) pp.allocs.push_back(*p);
@@ -218,22 +222,17 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels, bool side_s
     HIP_TRY(c, alloc((void **)&pp.fr.ray_d, node_cap * sizeof(float4)));
     HIP_TRY(c, alloc((void **)&pp.fr.link, node_cap * sizeof(uint2)));
     HIP_TRY(c, alloc((void **)&pp.fr.color, node_cap * sizeof(float4)));
-    HIP_TRY(c, alloc((void **)&pp.fr.shadow_q, (size_t)levels * nl * q_cap * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&pp.fr.wstack, (threads / 64) * ((size_t)wcap + SHADE_LIST) * sizeof(uint2)));
     HIP_TRY(c, alloc((void **)&pp.fr.counters, CTR_WORDS * sizeof(uint32_t)));
     HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
     // stack overflow beyond the LDS entries, sized from the uploaded tree (not MAX_TREE_DEPTH)
-    const size_t spill_bytes = (size_t)c->persistent_blocks * 256 * c->spill_entries * sizeof(uint32_t) * 2;  // (ref, t)
-    HIP_TRY(c, alloc((void **)&pp.fr.spill, spill_bytes));
-    if (side_spills)
-        for (auto &sp : pp.spill_side) HIP_TRY(c, alloc((void **)&sp, spill_bytes));
-    pp.side_spills = side_spills;
+    HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * c->spill_entries * sizeof(uint32_t) * 2));  // (ref, t)
     pp.spill_entries = c->spill_entries;
+    pp.wstack_cap = wcap;
+    pp.fr.wstack_cap = wcap;
     pp.node_cap = node_cap;
-    pp.q_cap = q_cap;
-    pp.lights = nl;
-    pp.levels = levels;
+    pp.n0_cap = n0;
     pp.fr.node_cap = (uint32_t)node_cap;
-    pp.fr.q_cap = (uint32_t)q_cap;
     return RTX_OK;
 }
 
@@ -262,6 +261,7 @@ int ensure_pixels(rtx_ctx *c, uint64_t npix, bool want_f32) {
 
 int ensure_counter_slots(rtx_ctx *c, uint32_t slots) {
     if (slots <= c->h_counter_slots) return RTX_OK;
+    for (auto &pp : c->pipes) HIP_TRY(c, hipStreamSynchronize(pp.main));  // an earlier render may still copy into the old block
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     c->h_counters = nullptr;
     HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, (size_t)slots * CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
@@ -291,55 +291,19 @@ struct Batch {
     uint32_t q0, npix, s0, ns;
 };
 
-// Runs the wavefront pipeline of one batch whose level-0 rays are already in the frame.
-// Per level: trace_closest -> shade_forward -> trace_shadow.  With `overlap`, trace_shadow of
-// a level goes to the side stream and runs beside the NEXT level's trace_closest (they touch
-// disjoint path nodes and per-level queues), so the tail of one persistent kernel -- a few
-// long rays -- is filled by the other instead of idling the GPU eight times per frame.
-// Records 4 timing events per level starting at events[ev0] when timing is on.
-int run_levels(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0, bool overlap) {
-    const size_t ns = pp.sides.size();
-    if (ns == 0) overlap = false;
-    while (overlap && pp.order.size() < (size_t)levels + ns) {
-        hipEvent_t e;
-        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        pp.order.push_back(e);
-    }
+// Runs the trace path of one batch whose primary rays are already in the frame: the persistent
+// path kernel (every ray of every bounce level), then the colours bottom-up, one streaming pass
+// per level.  Records 3 timing events starting at events[ev0] when timing is on: path begin, path
+// end, resolves end.
+int run_path(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
     lc.stream = pp.main;
-    for (uint32_t k = 0; k < levels; k++) {
-        // level 0's shadow launch is by far the longest: it has side stream 0 to itself, so
-        // that a deep level's short one does not queue behind it
-        const size_t sk = (k == 0 || ns == 1) ? 0 : 1 + (k - 1) % (ns - 1);
-        hipStream_t side = overlap ? pp.sides[sk] : pp.main;
-        LaunchCfg ls = lc;
-        ls.stream = side;
-        Frame fs = pp.fr;
-        if (overlap) fs.spill = pp.spill_side[sk];
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k], pp.main);
-        launch_trace_closest(c->ds, pp.fr, k, lc);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 1], pp.main);
-        launch_shade_forward(c->ds, pp.fr, k, levels, lc);
-        if (overlap) {
-            HIP_TRY(c, hipEventRecord(pp.order[k], pp.main));
-            HIP_TRY(c, hipStreamWaitEvent(side, pp.order[k], 0));
-        }
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 2], side);
-        launch_trace_shadow(c->ds, fs, k, ls);
-        if (timing) (void)hipEventRecord(c->events[ev0 + 4 * k + 3], side);
-        // hits without bounce children depend on nothing deeper: their colours are resolved
-        // as soon as the level's shadow answers exist, beside the deeper levels' traversal
-        if (overlap) launch_resolve(c->ds, pp.fr, k, RESOLVE_LEAVES, ls);
-    }
-    if (levels && overlap) {
-        for (size_t j = 0; j < std::min<size_t>(ns, levels); j++) {
-            HIP_TRY(c, hipEventRecord(pp.order[levels + j], pp.sides[j]));
-            HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.order[levels + j], 0));
-        }
-    }
-    // the deepest level spawns no children, so with `overlap` it is already complete
-    for (int k = (int)levels - (overlap ? 2 : 1); k >= 0; k--)
-        launch_resolve(c->ds, pp.fr, (uint32_t)k, overlap ? RESOLVE_PARENTS : RESOLVE_ALL, lc);
-    if (levels == 0) launch_resolve(c->ds, pp.fr, 0, RESOLVE_ALL, lc);
+    if (timing) (void)hipEventRecord(c->events[ev0], pp.main);
+    if (levels) launch_path(c->ds, pp.fr, levels, true, lc);   // trace_ray(.., 0) is the background (world.rs:116-117)
+    if (timing) (void)hipEventRecord(c->events[ev0 + 1], pp.main);
+    // a level deeper than 0 exists only if some material spawns bounce rays
+    for (int k = (c->max_bounce ? (int)levels - 1 : 0); k >= 1; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
+    launch_resolve(c->ds, pp.fr, 0, lc);
+    if (timing) (void)hipEventRecord(c->events[ev0 + 2], pp.main);
     return RTX_OK;
 }
 
@@ -367,19 +331,15 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     }
     uint32_t levels = bounces;
     uint32_t K = c->max_bounce;
-    uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 56 + geo_last(K, std::max(levels, 1u)) * 4 * std::max(c->ds.n_lights, 1u) * std::max(levels, 1u);
-    // Batches: the frame is cut into at least `P` independent pieces (by sample, else by pixel
-    // range) that run concurrently, one per pipe, so that the serial tail of every persistent
-    // kernel -- one ray can visit 500+ records against a mean of 9 -- overlaps another
-    // piece's bulk instead of idling the GPU.  The node budget is shared between the pipes.
-    // A launch ends with its longest ray (~0.1-0.5 ms alone on the GPU, eight launches per
-    // frame), so the kernels of one render run concurrently wherever the data allow it: the
-    // shadow kernels on side streams (run_levels) and, with RTX_PIPES > 1, batches on pipes.
+    uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 60;
+    // Batches: a frame whose path nodes exceed the node budget is cut into pieces (by sample, else
+    // by pixel range) that alternate between the pipes: the drain of one piece's persistent
+    // kernel -- it ends with its longest path -- and its resolve passes overlap the next piece's
+    // bulk.  The node budget is shared between the pipes.
     uint64_t total = pt.npix * spp;
-    bool overlap = total < c->overlap_below;
-    const size_t P = overlap ? c->pipes.size() : 1;
+    const size_t P = c->use_pipes ? c->pipes.size() : 1;
     uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / c->pipes.size() / per_sample, 4096);
-    const uint32_t want = total >= (1u << 20) ? (uint32_t)P : 1u;
+    const uint32_t want = total >= (1u << 20) ? std::max(1u, c->min_batches) : 1u;
     std::vector<Batch> batches;
     if (pt.npix <= cap0 && spp >= want) {
         uint32_t nsc = (uint32_t)std::min<uint64_t>(cap0 / std::max<uint64_t>(pt.npix, 1), (spp + want - 1) / want);
@@ -398,7 +358,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
     const size_t used = std::min(P, batches.size());
     for (size_t p = 0; p < used; p++) {
-        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u), overlap);
+        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
         if (rc != RTX_OK) return rc;
     }
     rc = ensure_pixels(c, pt.npix, want_f32);
@@ -408,7 +368,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     rc = ensure_chain(c, batches.size());
     if (rc != RTX_OK) return rc;
     bool timing = stats != nullptr;
-    size_t ev_per_batch = 4 * (size_t)levels;  // per level: closest begin/end, shadow begin/end
+    const size_t ev_per_batch = 3;  // path begin, path end, resolves end
     if (timing) {
         rc = ensure_events(c, ev_per_batch * batches.size());
         if (rc != RTX_OK) return rc;
@@ -445,7 +405,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         rc = reset_counters(c, pp);
         if (rc != RTX_OK) return rc;
         launch_raygen(c->ds, pp.fr, info, lc);
-        rc = run_levels(c, pp, lc, levels, timing, ev_per_batch * bi, overlap);
+        rc = run_path(c, pp, lc, levels, timing, ev_per_batch * bi);
         if (rc != RTX_OK) return rc;
         // sums are folded in sample order (world.rs:54-61): accumulate follows the previous batch's
         if (bi > 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->chain[bi - 1], 0));
@@ -456,13 +416,17 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     }
     if ((batches.size() - 1) % P != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->chain[batches.size() - 1], 0));
     HIP_TRY(c, hipGetLastError());
-    if (!stats && d_tiles_out) return RTX_OK;  // asynchronous device render
+    if (!stats && d_tiles_out) {  // asynchronous device render: rtx_synchronize looks at the overflow flags
+        c->pending_batches = (uint32_t)batches.size();
+        return RTX_OK;
+    }
+    c->pending_batches = 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     bool overflow = false;
     for (size_t bi = 0; bi < batches.size(); bi++)
         if (c->h_counters[bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
     if (overflow) {
-        c->err = "wavefront queue overflow (internal sizing error)";
+        c->err = "wavefront pool overflow (internal sizing error)";
         return RTX_ERR_CAPACITY;
     }
     if (stats) {
@@ -481,8 +445,8 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         stats->primary_rays = levels ? valid * spp : 0;
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const uint32_t *h = c->h_counters + bi * CTR_WORDS;
-            for (uint32_t k = 1; k < 8; k++) stats->bounce_rays += h[CTR_LEVEL_COUNT + k];
-            for (uint32_t k = 0; k < 8 * (uint32_t)MAX_LIGHTS; k++) stats->shadow_rays += h[CTR_SHADOW_COUNT + k];
+            stats->bounce_rays += (uint64_t)h[CTR_BOUNCE_LO] | ((uint64_t)h[CTR_BOUNCE_HI] << 32);
+            stats->shadow_rays += (uint64_t)h[CTR_SHADOW_LO] | ((uint64_t)h[CTR_SHADOW_HI] << 32);
             stats->closest_nodes += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
             stats->closest_prims += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
             stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
@@ -490,26 +454,17 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
             if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
                 const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
-                for (int k = 0; k < 2; k++)
-                    std::fprintf(stderr, "util %s node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu\n",
-                                 k ? "shadow" : "closest", (unsigned long long)u[5 * k], (unsigned long long)u[5 * k + 1],
-                                 (unsigned long long)u[5 * k + 2], (unsigned long long)u[5 * k + 3], (unsigned long long)u[5 * k + 4]);
+                std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu\n",
+                             (unsigned long long)u[0], (unsigned long long)u[1], (unsigned long long)u[2],
+                             (unsigned long long)u[3], (unsigned long long)u[4]);
             }
-            float span = 0;  // first trace launch begins .. last one ends (they overlap)
-            for (uint32_t k = 0; k < levels; k++) {
-                float ms = 0;
-                for (size_t e : {ev_per_batch * bi + 4 * k + 1, ev_per_batch * bi + 4 * k + 3})
-                    if (hipEventElapsedTime(&ms, c->events[ev_per_batch * bi], c->events[e]) == hipSuccess) span = std::max(span, ms);
+            float ms = 0;
+            const size_t e = ev_per_batch * bi;
+            if (levels && hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]) == hipSuccess) {
+                stats->path_kernel_ms += ms;
+                stats->path_launches++;
             }
-            stats->trace_span_ms += span;
-            for (uint32_t k = 0; k < levels; k++) {
-                float ms = 0;
-                size_t e = ev_per_batch * bi + 4 * k;
-                if (hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]) == hipSuccess) stats->closest_kernel_ms += ms;
-                if (hipEventElapsedTime(&ms, c->events[e + 2], c->events[e + 3]) == hipSuccess) stats->shadow_kernel_ms += ms;
-                stats->closest_launches++;
-                stats->shadow_launches++;
-            }
+            if (hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]) == hipSuccess) stats->resolve_ms += ms;
         }
     }
     return RTX_OK;
@@ -540,19 +495,12 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     rtx_ctx *c = new rtx_ctx();
     c->device = device;
-    int n_pipes = 1;
+    int n_pipes = 2;
     if (const char *np = std::getenv("RTX_PIPES")) n_pipes = std::min(4, std::max(1, std::atoi(np)));
-    int n_sides = 3;
-    if (const char *ns = std::getenv("RTX_SIDES")) n_sides = std::min(4, std::max(0, std::atoi(ns)));
     c->pipes.resize((size_t)n_pipes);
     e = hipEventCreateWithFlags(&c->start_ev, hipEventDisableTiming);
-    for (auto &pp : c->pipes) {
+    for (auto &pp : c->pipes)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.main, hipStreamNonBlocking);
-        pp.sides.assign((size_t)n_sides, nullptr);
-        pp.spill_side.assign((size_t)n_sides, nullptr);
-        for (auto &sd : pp.sides)
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&sd, hipStreamNonBlocking);
-    }
     if (e != hipSuccess) {
         g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         rtx_destroy(c);
@@ -571,8 +519,9 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
-    if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: never, 1: always
-        c->overlap_below = std::atoi(ov) ? ~0ull : 0ull;
+    if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: every batch on one stream
+        c->use_pipes = std::atoi(ov) != 0;
+    if (const char *mn = std::getenv("RTX_MIN_BATCHES")) c->min_batches = (uint32_t)std::min(64, std::max(1, std::atoi(mn)));
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
         long v = std::atol(mb);
         if (v > 0) c->node_budget_bytes = (uint64_t)v << 20;
@@ -584,18 +533,12 @@ int rtx_init(int device, rtx_ctx **out) {
 void rtx_destroy(rtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (auto &pp : c->pipes) {
+    for (auto &pp : c->pipes)
         if (pp.main) (void)hipStreamSynchronize(pp.main);
-        for (auto sd : pp.sides)
-            if (sd) (void)hipStreamSynchronize(sd);
-    }
     free_all(c->scene_allocs);
     for (auto &pp : c->pipes) {
         free_all(pp.allocs);
-        for (auto e : pp.order) (void)hipEventDestroy(e);
         if (pp.main) (void)hipStreamDestroy(pp.main);
-        for (auto sd : pp.sides)
-            if (sd) (void)hipStreamDestroy(sd);
     }
     if (c->sum) (void)hipFree(c->sum);
     if (c->tiles) (void)hipFree(c->tiles);
@@ -676,6 +619,9 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     c->leaf_order = std::move(bvh.leaf_order);
     c->preorder_sizes = std::move(fs.preorder_sizes);
     c->max_bounce = fs.max_bounce;
+    ds.max_bounce = fs.max_bounce;
+    c->per_hit = fs.max_bounce;
+    for (const auto &l : fs.lights) c->per_hit += l.type != LIGHT_AMBIENT ? 1u : 0u;
     c->info.n_objects = d->n_objects;
     c->info.n_internal = (uint32_t)fs.nodes.size();
     c->info.n_leaves = fs.n_leaves;
@@ -727,6 +673,15 @@ void *rtx_stream(rtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int rtx_synchronize(rtx_ctx *c) {
     if (!c) return RTX_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // an asynchronous rtx_render_device returned before its counters were back: report its overflow here
+    bool overflow = false;
+    for (uint32_t bi = 0; bi < c->pending_batches && bi < c->h_counter_slots; bi++)
+        if (c->h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
+    c->pending_batches = 0;
+    if (overflow) {
+        c->err = "wavefront pool overflow in the last asynchronous render (internal sizing error)";
+        return RTX_ERR_CAPACITY;
+    }
     return RTX_OK;
 }
 
@@ -759,16 +714,15 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     // ONE batch whose wavefront buffers are carved out of the static scratch array; a grid of at
     // most one block per CU keeps the stack-spill part of it small
     const uint32_t levels = bounces, lv = std::max(levels, 1u), K = c->max_bounce;
-    const uint32_t nl = std::max<uint32_t>(c->ds.n_lights, 1);
     const int blocks = std::min(c->persistent_blocks, 256);
     const uint64_t n0 = std::max<uint64_t>(pt.npix * spp, 1);
     const long double est = (long double)n0 * (long double)geo_sum(K, lv);
-    Pipe np;  // no streams or events of its own: the serial schedule on rtx_stream()
+    Pipe np;  // no stream or events of its own: runs on rtx_stream()
     float4 *sum = nullptr;
     size_t need = ~(size_t)0;
     if (est < 4.0e9L)
-        need = layout_frame(c->scratch, n0 * geo_sum(K, lv), n0 * geo_last(K, lv), lv, nl, (size_t)blocks * 256,
-                            c->spill_entries, pt.npix, np.fr, &sum);
+        need = layout_frame(c->scratch, n0, node_capacity(c, n0, lv, (size_t)blocks * 256), (size_t)blocks * 256,
+                            c->spill_entries, wstack_capacity(c, lv), pt.npix, np.fr, &sum);
     if (need > NOALLOC_SCRATCH_BYTES) {
         char msg[256];
         std::snprintf(msg, sizeof msg,
@@ -801,7 +755,7 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     rc = reset_counters(c, np);
     if (rc != RTX_OK) return rc;
     launch_raygen(c->ds, np.fr, info, lc);
-    rc = run_levels(c, np, lc, levels, false, 0, false);
+    rc = run_path(c, np, lc, levels, false, 0);
     if (rc != RTX_OK) return rc;
     launch_accumulate(c->ds, np.fr, info, sum, static_cast<uint8_t *>(d_tiles), nullptr, lc);
     HIP_TRY(c, hipGetLastError());
@@ -886,7 +840,7 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
         info.max_levels = 1;
         (void)reset_counters(c, pp);
         launch_raygen(c->ds, pp.fr, info, lc);
-        launch_trace_closest(c->ds, pp.fr, 0, lc);
+        launch_path(c->ds, pp.fr, 1, false, lc);
         launch_export_hits(c->ds, pp.fr, n, d_obj, d_t, lc);
         hipError_t e = hipMemcpyAsync(h_obj.data(), d_obj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_t.data(), d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
@@ -939,11 +893,11 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         (void)reset_counters(c, pp);
         launch_load_rays(pp.fr, d_rays, m, lc);
         if (out_rgb) {
-            if (run_levels(c, pp, lc, levels, false, 0, false) != RTX_OK) e = hipErrorUnknown;
+            if (run_path(c, pp, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
             launch_export_colors(pp.fr, m, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
         } else {
-            launch_trace_closest(c->ds, pp.fr, 0, lc);
+            launch_path(c->ds, pp.fr, 1, false, lc);
             launch_export_hits(c->ds, pp.fr, m, d_obj, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_obj + i0, d_obj, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(out_t + i0, d_f, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream);

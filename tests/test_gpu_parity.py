@@ -373,12 +373,14 @@ def test_sample_batching_is_exact(rt, gpu, monkeypatch):
 
 
 def test_concurrent_and_serial_schedules_agree(rt, gpu, monkeypatch):
-    """Side streams + two pipes and the fully serial schedule must not differ in a byte."""
+    """Batches alternating between two pipes (concurrent streams) and one batch on one stream must
+    not differ in a byte."""
     s = rt.HostScene("scan_glass", 512, 30000)
     imgs = []
     for mode in ("0", "1"):
         monkeypatch.setenv("RTX_CONCURRENT", mode)
         monkeypatch.setenv("RTX_PIPES", "2")
+        monkeypatch.setenv("RTX_MIN_BATCHES", "3" if mode == "1" else "1")
         c = rt.Context(0)
         try:
             c.upload(s)

@@ -9,4 +9,4 @@ ctx.upload(s)
 tiles = torch.zeros(ctx.partition_pixels(None) * 3, dtype=torch.uint8, device="cuda")
 st = ctx.render_device(tiles.data_ptr(), 16, 4, seed=1, flags=rt.FLAG_COUNT_VISITS)
 print("rays", st.rays, "closest n/p", st.closest_nodes, st.closest_prims, "shadow n/p", st.shadow_nodes, st.shadow_prims,
-      "max records by one ray", st.max_ray_records, "closest ms", round(st.closest_kernel_ms, 1), "shadow ms", round(st.shadow_kernel_ms, 1))
+      "max records by one ray", st.max_ray_records, "path ms", round(st.path_kernel_ms, 1), "resolve ms", round(st.resolve_ms, 1))
