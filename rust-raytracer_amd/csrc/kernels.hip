@@ -636,6 +636,7 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 // tools/util_probe.py prints it): wave steps and executing lanes per kind.
 struct Util {
     uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
+    uint32_t events = 0, shade_events = 0, shade_lanes = 0, start_lanes = 0, fin_lanes = 0;  // path kernel: lanes-between-rays events
     __device__ __forceinline__ void flush(uint32_t *ctr) {
 #ifdef RTX_UTIL_STATS
         if (lane_id() == 0) {
@@ -645,6 +646,11 @@ struct Util {
             atomicAdd(c + 2, (unsigned long long)node_lanes);
             atomicAdd(c + 3, (unsigned long long)prim_lanes);
             atomicAdd(c + 4, (unsigned long long)done_lanes);
+            atomicAdd(c + 5, (unsigned long long)events);
+            atomicAdd(c + 6, (unsigned long long)shade_events);
+            atomicAdd(c + 7, (unsigned long long)shade_lanes);
+            atomicAdd(c + 8, (unsigned long long)start_lanes);
+            atomicAdd(c + 9, (unsigned long long)fin_lanes);
         }
 #endif
     }
@@ -682,6 +688,15 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #ifndef RTX_REFILL_MIN
 #define RTX_REFILL_MIN 32
 #endif
+// Queue entries a wave reserves with one atomic.  An entry is a primary sample with its whole path
+// tree (about 4.6 rays on the headline frame), walked by that wave alone: long runs in a costly
+// part of the image (silhouettes: rays of hundreds of steps) make stragglers.
+#ifndef RTX_CHUNK_MIN
+#define RTX_CHUNK_MIN 32
+#endif
+#ifndef RTX_CHUNK_MAX
+#define RTX_CHUNK_MAX 64
+#endif
 struct WaveQueue {
     uint32_t *heads;
     uint32_t count, chunk, psize, nwaves, p0, tried;
@@ -700,7 +715,7 @@ struct WaveQueue {
         count = n;
         nwaves = nw;
         uint32_t c = n / (nwaves * 4u);
-        chunk = c < 64u ? 64u : (c > 256u ? 256u : c);
+        chunk = c < (uint32_t)RTX_CHUNK_MIN ? (uint32_t)RTX_CHUNK_MIN : (c > (uint32_t)RTX_CHUNK_MAX ? (uint32_t)RTX_CHUNK_MAX : c);
         psize = ((n + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS + 63u) & ~63u;
         p0 = wave % (uint32_t)QPARTS;
         tried = 0;
@@ -968,6 +983,11 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
             continue;
         }
+#ifdef RTX_UTIL_STATS
+        util.events++;
+        util.fin_lanes += nfin;
+        if (wq.exhausted && t_dry == 0) t_dry = wall_clock64();
+#endif
         // ---- the rays that have just finished
         if (nfin != 0u) {
             if (SHADE && fin && (tag & WK_SHADOW)) {
@@ -1010,6 +1030,10 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             if (shn >= (uint32_t)RTX_SHADE_MIN || shn > (uint32_t)SHADE_LIST - 64u || (shn != 0u && wq.exhausted && top < nidle)) {
                 const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
                 const uint32_t n_sh = nidle < shn ? nidle : shn;
+#ifdef RTX_UTIL_STATS
+                util.shade_events++;
+                util.shade_lanes += n_sh;
+#endif
                 const bool mine = idle && rank < n_sh;
                 uint32_t hnode = 0, level = 0, hprim = 0, lit0 = 0, want = 0, nb = 0;
                 F3 p = f3(0.f, 0.f, 0.f), d = p;
@@ -1030,6 +1054,25 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                     else if (L.type != LIGHT_CONE || !outside_cone(L, p)) want |= 1u << l;
                 }
                 if (!mine) lit0 = want = 0;
+                // shadow queries, light by light (a light's queries are popped together); the bounce children go on
+                // top of them: the longest chain of a sample -- closest hit after closest hit down the
+                // bounce levels -- is not held up by the shadow queries on the way
+                for (uint32_t l = 0; l < sc.n_lights; l++) {
+                    const bool wl = (want >> l) & 1u;
+                    const unsigned long long m = __ballot(wl);
+                    if (m == 0ull) continue;
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    if (top + cnt > wk_cap) {
+                        if (lane == 0) fr.counters[CTR_OVERFLOW] = 1;
+                        continue;
+                    }
+                    if (wl)
+                        wk[top + (uint32_t)__popcll(m & lt_mask)] =
+                            make_uint2(hnode, l | (sc.lights[l].type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
+                                                  (level << WK_LEVEL_SHIFT));
+                    top += cnt;
+                    n_shadow += cnt;
+                }
                 // bounce children: path nodes from this wave's run of the pool
                 uint32_t first = NO_PRIM;
                 const unsigned long long b0 = __ballot(nb & 1u), b1 = __ballot(nb & 2u), b2 = __ballot(nb & 4u);
@@ -1075,23 +1118,6 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                     }
                 }
                 if (mine) fr.link[hnode] = make_uint2(lit0 | (level << LINK_LEVEL_SHIFT) | (nb << LINK_NB_SHIFT), first);
-                // shadow queries, light by light, on top of the children: they are traced next
-                for (uint32_t l = 0; l < sc.n_lights; l++) {
-                    const bool wl = (want >> l) & 1u;
-                    const unsigned long long m = __ballot(wl);
-                    if (m == 0ull) continue;
-                    const uint32_t cnt = (uint32_t)__popcll(m);
-                    if (top + cnt > wk_cap) {
-                        if (lane == 0) fr.counters[CTR_OVERFLOW] = 1;
-                        continue;
-                    }
-                    if (wl)
-                        wk[top + (uint32_t)__popcll(m & lt_mask)] =
-                            make_uint2(hnode, l | (sc.lights[l].type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
-                                                  (level << WK_LEVEL_SHIFT));
-                    top += cnt;
-                    n_shadow += cnt;
-                }
             }
         }
         // ---- work for the idle lanes: the top of the wave's stack first, then new primaries
@@ -1119,13 +1145,23 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 const unsigned long long wmask = __ballot(wants);
                 if (wmask != 0ull) {
                     uint32_t i = 0;
-                    if (wq.take(wmask, wants, i)) {
-                        node = i;
-                        tag = WK_BUSY;  // closest-hit query, level 0
-                        got = true;
+                    // (a run of the queue may end in the middle: the rest of the lanes take from the next one)
+                    bool unserved = wants;
+                    for (int round = 0; round < 4 && !wq.exhausted; round++) {
+                        const unsigned long long um = __ballot(unserved);
+                        if (um == 0ull) break;
+                        if (wq.take(um, unserved, i)) {
+                            node = i;
+                            tag = WK_BUSY;  // closest-hit query, level 0
+                            got = true;
+                            unserved = false;
+                        }
                     }
                 }
             }
+#ifdef RTX_UTIL_STATS
+            util.start_lanes += (uint32_t)__popcll(__ballot(got));
+#endif
             // ---- begin the new rays
             if (got) {
                 const float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
@@ -1167,6 +1203,17 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         }
     }
     util.flush(fr.counters);
+#ifdef RTX_UTIL_STATS
+    if (lane == 0) {  // wave lifetimes in 100 MHz ticks: [10] earliest begin, [11] latest end, [12] sum of lifetimes, [13] sum of time after the queue ran dry
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(fr.counters + CTR_UTIL);
+        const unsigned long long t_end = wall_clock64();
+        atomicMin(c + 10, t_begin);
+        atomicMax(c + 11, t_end);
+        atomicAdd(c + 12, t_end - t_begin);
+        atomicAdd(c + 13, t_dry ? t_end - t_dry : 0ull);
+        atomicMax(c + 14, t_dry ? t_end - t_dry : 0ull);
+    }
+#endif
     if (COUNT) {
         add_visits(fr.counters, vis_cn, vis_cp, CTR_VISIT_NODES_LO);
         add_visits(fr.counters, vis_sn, vis_sp, CTR_SVISIT_NODES_LO);

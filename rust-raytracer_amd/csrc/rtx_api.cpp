@@ -239,6 +239,7 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
 int reset_counters(rtx_ctx *c, Pipe &pp) {
     HIP_TRY(c, hipMemsetAsync(pp.fr.counters, 0, CTR_WORDS * sizeof(uint32_t), pp.main));
     HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, WORK_WORDS * sizeof(uint32_t), pp.main));
+    HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_UTIL + 20, 0xFF, 8, pp.main));  // earliest wave begin (diagnostic builds): atomicMin
     return RTX_OK;
 }
 
@@ -454,9 +455,15 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
             stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
             if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
                 const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
-                std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu\n",
+                std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu "
+                                     "events %llu shade_events %llu shade_lanes %llu start_lanes %llu fin_lanes %llu\n",
                              (unsigned long long)u[0], (unsigned long long)u[1], (unsigned long long)u[2],
-                             (unsigned long long)u[3], (unsigned long long)u[4]);
+                             (unsigned long long)u[3], (unsigned long long)u[4], (unsigned long long)u[5],
+                             (unsigned long long)u[6], (unsigned long long)u[7], (unsigned long long)u[8],
+                             (unsigned long long)u[9]);
+                std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms, mean / max time after the queue ran dry %.3f / %.3f ms\n",
+                             (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
+                             (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
             }
             float ms = 0;
             const size_t e = ev_per_batch * bi;
