@@ -156,6 +156,21 @@ int rtx_render(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
 int rtx_render_device(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
                       const rtx_partition *part_or_null, uint32_t flags,
                       void *d_tiles_rgb8, rtx_stats *stats_or_null);
+/* Render slots: a context holds rtx_slot_count() (2; RTX_PIPES) independent slots, each with its own
+ * stream and wavefront buffers, so that consecutive frames -- or the tile shares of a multi-GPU
+ * frame sequence -- overlap on the GPU: a render ends with a drain of a few long rays that leaves
+ * most of the machine idle, and the next frame's bulk fills it (the thread pool of world.rs:38-68
+ * keeps its workers busy the same way, column by column).  rtx_render_device(...) is slot 0.
+ * Renders in one slot follow each other on rtx_slot_stream(slot); order consumers of d_tiles after
+ * that stream, and do not reuse one d_tiles buffer for two slots in flight.  No counterpart in
+ * the reference. */
+int rtx_slot_count(rtx_ctx *ctx);
+int rtx_render_device_slot(rtx_ctx *ctx, uint32_t slot, uint32_t spp, uint32_t max_bounces, uint64_t seed,
+                           const rtx_partition *part_or_null, uint32_t flags,
+                           void *d_tiles_rgb8, rtx_stats *stats_or_null);
+void *rtx_slot_stream(rtx_ctx *ctx, uint32_t slot);
+int rtx_slot_synchronize(rtx_ctx *ctx, uint32_t slot);
+
 /* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result bytes as
  * rtx_render_device, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no event:
@@ -171,8 +186,8 @@ int rtx_render_device_noalloc(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, 
                               const rtx_partition *part_or_null, uint32_t flags, void *d_tiles_rgb8);
 /* Number of pixel slots (tiles * tile * tile) this rank owns under `part`. */
 uint64_t rtx_partition_pixels(rtx_ctx *ctx, const rtx_partition *part_or_null);
-void *rtx_stream(rtx_ctx *ctx); /* hipStream_t the kernels are launched on */
-int rtx_synchronize(rtx_ctx *ctx);
+void *rtx_stream(rtx_ctx *ctx); /* hipStream_t of slot 0: rtx_render_device, rtx_render_device_noalloc, the trace calls */
+int rtx_synchronize(rtx_ctx *ctx); /* waits for every slot; reports a capacity overflow of an asynchronous render */
 
 /* Hit-ID parity: closest hit of the primary ray of sample `sample` of every pixel
  * (camera.rs:32-47 + bvh.rs:33-35).  out_obj: object index in rtx_scene_desc order,

@@ -98,6 +98,12 @@ def lib():
                                     C.POINTER(Stats)]
     L.rtx_render_device_noalloc.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32, vp]
     L.rtx_set_build_threads.argtypes = [vp, C.c_int]
+    L.rtx_render_device_slot.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32,
+                                         vp, C.POINTER(Stats)]
+    L.rtx_slot_count.argtypes = [vp]
+    L.rtx_slot_stream.argtypes = [vp, C.c_uint32]
+    L.rtx_slot_stream.restype = vp
+    L.rtx_slot_synchronize.argtypes = [vp, C.c_uint32]
     L.rtx_partition_pixels.argtypes = [vp, C.POINTER(Partition)]
     L.rtx_partition_pixels.restype = C.c_uint64
     L.rtx_stream.argtypes = [vp]
@@ -355,12 +361,22 @@ class Context:
         p = C.byref(Partition(*part)) if part else None
         return lib().rtx_partition_pixels(self._h, p)
 
-    def render_device(self, d_ptr, spp=1, bounces=4, seed=0, part=None, flags=0, stats=True):
+    def render_device(self, d_ptr, spp=1, bounces=4, seed=0, part=None, flags=0, stats=True, slot=0):
         st = Stats()
         p = C.byref(Partition(*part)) if part else None
-        self._check(lib().rtx_render_device(self._h, spp, bounces, seed, p, flags, C.c_void_p(d_ptr),
-                                            C.byref(st) if stats else None))
+        self._check(lib().rtx_render_device_slot(self._h, slot, spp, bounces, seed, p, flags, C.c_void_p(d_ptr),
+                                                 C.byref(st) if stats else None))
         return st
+
+    @property
+    def slots(self):
+        return self._check(lib().rtx_slot_count(self._h))
+
+    def slot_stream(self, slot):
+        return int(lib().rtx_slot_stream(self._h, slot) or 0)
+
+    def slot_synchronize(self, slot):
+        self._check(lib().rtx_slot_synchronize(self._h, slot))
 
     def render_device_noalloc(self, d_ptr, spp=1, bounces=4, seed=0, part=None, flags=0):
         """rtx_render_device_noalloc: wavefront state in the library's static device array (asynchronous)."""

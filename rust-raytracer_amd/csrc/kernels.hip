@@ -960,6 +960,11 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     Util util;
     WaveQueue wq;
     wq.init(fr.work, n0, nthreads / 64u, gtid / 64u);
+#ifdef RTX_UTIL_STATS
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_dry = 0;
+    uint32_t dry_events = 0, dry_steps0 = 0, dry_fin = 0, dry_top = 0, dry_fin_c = 0;
+#endif
     for (;;) {
         const bool idle = s.cur == TRAV_DONE;
         const bool fin = idle && (tag & WK_BUSY);
@@ -986,7 +991,16 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
 #ifdef RTX_UTIL_STATS
         util.events++;
         util.fin_lanes += nfin;
-        if (wq.exhausted && t_dry == 0) t_dry = wall_clock64();
+        if (wq.exhausted && t_dry == 0) {
+            t_dry = wall_clock64();
+            dry_steps0 = util.node_steps + util.prim_steps;
+            dry_top = top + shn + nact;
+        }
+        if (t_dry) {
+            dry_events++;
+            dry_fin += nfin;
+            dry_fin_c += (uint32_t)__popcll(__ballot(fin && !(tag & WK_SHADOW)));
+        }
 #endif
         // ---- the rays that have just finished
         if (nfin != 0u) {
@@ -1212,6 +1226,19 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         atomicAdd(c + 12, t_end - t_begin);
         atomicAdd(c + 13, t_dry ? t_end - t_dry : 0ull);
         atomicMax(c + 14, t_dry ? t_end - t_dry : 0ull);
+        if (t_dry && t_end - t_dry > 60000ull) {  // > 0.6 ms after the queue ran dry: a straggler, listed behind the counters
+            uint32_t *dbg = fr.counters + CTR_WORDS;
+            const uint32_t k = atomicAdd(dbg, 1u);
+            if (k < 40u) {
+                uint32_t *r = dbg + 1 + 6 * k;
+                r[0] = (uint32_t)(t_end - t_dry);
+                r[1] = dry_events;
+                r[2] = util.node_steps + util.prim_steps - dry_steps0;
+                r[3] = dry_fin;
+                r[4] = dry_top;
+                r[5] = dry_fin_c;
+            }
+        }
     }
 #endif
     if (COUNT) {

@@ -25,21 +25,27 @@ double now_s() {
 }
 }  // namespace
 
-// One in-flight batch: its wavefront buffers and the stream its kernels run on.
+// One render slot: a stream, the wavefront buffers of the batch in flight on it, and what a
+// render needs besides -- renders in different slots do not share anything they write, so
+// their kernels overlap on the GPU (one slot's drain and resolve passes under the other's bulk).
 struct Pipe {
     Frame fr{};
     std::vector<void *> allocs;
     uint64_t n0_cap = 0, node_cap = 0;
     uint32_t spill_entries = 0, wstack_cap = 0;
     hipStream_t main = nullptr;
+    float4 *sum = nullptr;            // per-pixel sums of a render cut into several batches
+    uint64_t pix_cap = 0;
+    uint32_t *h_counters = nullptr;   // pinned, one CTR_WORDS block per batch
+    uint32_t h_counter_slots = 0;
+    std::vector<hipEvent_t> events;   // timing (renders with stats)
+    uint32_t pending_batches = 0;     // batches of the last asynchronous render whose overflow flags nobody has looked at
 };
 
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     // = pipes[0].main, the stream rtx_stream() hands out
-    std::vector<Pipe> pipes;          // batches of one render are dealt round-robin over the pipes
-    std::vector<hipEvent_t> chain;    // per batch: "accumulated and counters copied" (ordering only)
-    hipEvent_t start_ev = nullptr;
+    std::vector<Pipe> pipes;          // the render slots (rtx_render_device_slot); everything else uses slot 0
     std::string err;
     int persistent_blocks = 1024;
     // scene
@@ -50,22 +56,16 @@ struct rtx_ctx {
     rtx_bvh_info info{};
     uint32_t max_bounce = 0;
     uint32_t per_hit = 0;             // work entries one closest hit can push: bounce children + non-ambient lights
-    // per-render state
-    float4 *sum = nullptr;
+    // host-image renders (rtx_render, slot 0)
     uint8_t *tiles = nullptr;
     float *tiles_f32 = nullptr;
-    uint64_t pix_cap = 0;
-    uint32_t *h_counters = nullptr;  // pinned, one CTR_WORDS block per batch
-    uint32_t h_counter_slots = 0;
-    std::vector<hipEvent_t> events;
+    uint64_t tiles_cap = 0;
     uint64_t node_budget_bytes = 32ull << 30;
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
     int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
     uint8_t *scratch = nullptr;       // this device's copy of the static scratch array (rtx_render_device_noalloc)
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
-    uint32_t pending_batches = 0;     // batches of the last asynchronous render whose overflow flags nobody has looked at
-    bool use_pipes = true;            // batches of a render alternate between the pipes (RTX_CONCURRENT=0: one pipe)
 };
 
 namespace {
@@ -223,7 +223,7 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&pp.fr.link, node_cap * sizeof(uint2)));
     HIP_TRY(c, alloc((void **)&pp.fr.color, node_cap * sizeof(float4)));
     HIP_TRY(c, alloc((void **)&pp.fr.wstack, (threads / 64) * ((size_t)wcap + SHADE_LIST) * sizeof(uint2)));
-    HIP_TRY(c, alloc((void **)&pp.fr.counters, CTR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(c, alloc((void **)&pp.fr.counters, (CTR_WORDS + 256) * sizeof(uint32_t)));  // (+ straggler list of diagnostic builds)
     HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
     // stack overflow beyond the LDS entries, sized from the uploaded tree (not MAX_TREE_DEPTH)
     HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * c->spill_entries * sizeof(uint32_t) * 2));  // (ref, t)
@@ -238,52 +238,48 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
 
 int reset_counters(rtx_ctx *c, Pipe &pp) {
     HIP_TRY(c, hipMemsetAsync(pp.fr.counters, 0, CTR_WORDS * sizeof(uint32_t), pp.main));
+    if (std::getenv("RTX_UTIL_PRINT") && pp.allocs.size()) HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_WORDS, 0, 256 * sizeof(uint32_t), pp.main));
     HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, WORK_WORDS * sizeof(uint32_t), pp.main));
     HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_UTIL + 20, 0xFF, 8, pp.main));  // earliest wave begin (diagnostic builds): atomicMin
     return RTX_OK;
 }
 
-int ensure_pixels(rtx_ctx *c, uint64_t npix, bool want_f32) {
-    if (npix > c->pix_cap || !c->sum) {
-        if (c->sum) (void)hipFree(c->sum);
+int ensure_pixels(rtx_ctx *c, Pipe &pp, uint64_t npix, bool own_tiles, bool want_f32) {
+    if (npix > pp.pix_cap || !pp.sum) {
+        HIP_TRY(c, hipStreamSynchronize(pp.main));
+        if (pp.sum) (void)hipFree(pp.sum);
+        pp.sum = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&pp.sum, std::max<size_t>(npix * sizeof(float4), 256)));
+        pp.pix_cap = npix;
+    }
+    if (own_tiles && (npix > c->tiles_cap || !c->tiles)) {
         if (c->tiles) (void)hipFree(c->tiles);
         if (c->tiles_f32) (void)hipFree(c->tiles_f32);
-        c->sum = nullptr;
         c->tiles = nullptr;
         c->tiles_f32 = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&c->sum, std::max<size_t>(npix * sizeof(float4), 256)));
         HIP_TRY(c, hipMalloc((void **)&c->tiles, std::max<size_t>(npix * 3, 256)));
-        c->pix_cap = npix;
+        c->tiles_cap = npix;
     }
-    if (want_f32 && !c->tiles_f32)
-        HIP_TRY(c, hipMalloc((void **)&c->tiles_f32, std::max<size_t>(c->pix_cap * 3 * sizeof(float), 256)));
+    if (own_tiles && want_f32 && !c->tiles_f32)
+        HIP_TRY(c, hipMalloc((void **)&c->tiles_f32, std::max<size_t>(c->tiles_cap * 3 * sizeof(float), 256)));
     return RTX_OK;
 }
 
-int ensure_counter_slots(rtx_ctx *c, uint32_t slots) {
-    if (slots <= c->h_counter_slots) return RTX_OK;
-    for (auto &pp : c->pipes) HIP_TRY(c, hipStreamSynchronize(pp.main));  // an earlier render may still copy into the old block
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    c->h_counters = nullptr;
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, (size_t)slots * CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    c->h_counter_slots = slots;
+int ensure_counter_slots(rtx_ctx *c, Pipe &pp, uint32_t slots) {
+    if (slots <= pp.h_counter_slots) return RTX_OK;
+    HIP_TRY(c, hipStreamSynchronize(pp.main));  // an earlier render may still copy into the old block
+    if (pp.h_counters) (void)hipHostFree(pp.h_counters);
+    pp.h_counters = nullptr;
+    HIP_TRY(c, hipHostMalloc((void **)&pp.h_counters, (size_t)slots * CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    pp.h_counter_slots = slots;
     return RTX_OK;
 }
 
-int ensure_events(rtx_ctx *c, size_t n) {
-    while (c->events.size() < n) {
+int ensure_events(rtx_ctx *c, Pipe &pp, size_t n) {
+    while (pp.events.size() < n) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreate(&e));
-        c->events.push_back(e);
-    }
-    return RTX_OK;
-}
-
-int ensure_chain(rtx_ctx *c, size_t n) {
-    while (c->chain.size() < n) {
-        hipEvent_t e;
-        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->chain.push_back(e);
+        pp.events.push_back(e);
     }
     return RTX_OK;
 }
@@ -298,21 +294,25 @@ struct Batch {
 // end, resolves end.
 int run_path(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
     lc.stream = pp.main;
-    if (timing) (void)hipEventRecord(c->events[ev0], pp.main);
+    if (timing) (void)hipEventRecord(pp.events[ev0], pp.main);
     if (levels) launch_path(c->ds, pp.fr, levels, true, lc);   // trace_ray(.., 0) is the background (world.rs:116-117)
-    if (timing) (void)hipEventRecord(c->events[ev0 + 1], pp.main);
+    if (timing) (void)hipEventRecord(pp.events[ev0 + 1], pp.main);
     // a level deeper than 0 exists only if some material spawns bounce rays
     for (int k = (c->max_bounce ? (int)levels - 1 : 0); k >= 1; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
     launch_resolve(c->ds, pp.fr, 0, lc);
-    if (timing) (void)hipEventRecord(c->events[ev0 + 2], pp.main);
+    if (timing) (void)hipEventRecord(pp.events[ev0 + 2], pp.main);
     return RTX_OK;
 }
 
-int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part, uint32_t flags,
-                void *d_tiles_out, bool want_f32, rtx_stats *stats, Partition &pt) {
+int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
+                uint32_t flags, void *d_tiles_out, bool want_f32, rtx_stats *stats, Partition &pt) {
     if (!c->has_scene) {
         c->err = "no scene uploaded";
         return RTX_ERR_NO_SCENE;
+    }
+    if (slot >= c->pipes.size()) {
+        c->err = "render slot out of range (rtx_slot_count)";
+        return RTX_ERR_INVALID;
     }
     flags |= c->force_flags;
     if (spp == 0) {
@@ -330,15 +330,13 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         c->err = "more than 2^32 pixel slots per rank";
         return RTX_ERR_CAPACITY;
     }
+    Pipe &pp = c->pipes[slot];
     uint32_t levels = bounces;
     uint32_t K = c->max_bounce;
     uint64_t per_sample = geo_sum(K, std::max(levels, 1u)) * 60;
-    // Batches: a frame whose path nodes exceed the node budget is cut into pieces (by sample, else
-    // by pixel range) that alternate between the pipes: the drain of one piece's persistent
-    // kernel -- it ends with its longest path -- and its resolve passes overlap the next piece's
-    // bulk.  The node budget is shared between the pipes.
+    // Batches: a frame whose path nodes exceed the slot's share of the node budget is cut into
+    // pieces (by sample, else by pixel range) that run one after the other on the slot's stream.
     uint64_t total = pt.npix * spp;
-    const size_t P = c->use_pipes ? c->pipes.size() : 1;
     uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / c->pipes.size() / per_sample, 4096);
     const uint32_t want = total >= (1u << 20) ? std::max(1u, c->min_batches) : 1u;
     std::vector<Batch> batches;
@@ -357,36 +355,28 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
     if (batches.empty()) batches.push_back(Batch{0, 0, 0, spp});
     uint64_t n0max = 0;
     for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
-    const size_t used = std::min(P, batches.size());
-    for (size_t p = 0; p < used; p++) {
-        rc = ensure_frame(c, c->pipes[p], std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
-        if (rc != RTX_OK) return rc;
-    }
-    rc = ensure_pixels(c, pt.npix, want_f32);
+    rc = ensure_frame(c, pp, std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
     if (rc != RTX_OK) return rc;
-    rc = ensure_counter_slots(c, (uint32_t)batches.size());
+    rc = ensure_pixels(c, pp, pt.npix, d_tiles_out == nullptr, want_f32);
     if (rc != RTX_OK) return rc;
-    rc = ensure_chain(c, batches.size());
+    rc = ensure_counter_slots(c, pp, (uint32_t)batches.size());
     if (rc != RTX_OK) return rc;
     bool timing = stats != nullptr;
     const size_t ev_per_batch = 3;  // path begin, path end, resolves end
     if (timing) {
-        rc = ensure_events(c, ev_per_batch * batches.size());
+        rc = ensure_events(c, pp, ev_per_batch * batches.size());
         if (rc != RTX_OK) return rc;
     }
-    LaunchCfg lc{c->stream, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
+    LaunchCfg lc{pp.main, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
                  (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
     uint8_t *tiles = d_tiles_out ? static_cast<uint8_t *>(d_tiles_out) : c->tiles;
     double t0 = 0;
     if (timing) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(pp.main));
         t0 = now_s();
     }
-    HIP_TRY(c, hipEventRecord(c->start_ev, c->stream));
     for (size_t bi = 0; bi < batches.size(); bi++) {
         const Batch &b = batches[bi];
-        Pipe &pp = c->pipes[bi % P];
-        lc.stream = pp.main;
         BatchInfo info{};
         info.q0 = b.q0;
         info.npix = b.npix;
@@ -402,30 +392,26 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         info.tiles_x = pt.tiles_x;
         info.tiles_y = pt.tiles_y;
         info.max_levels = levels;
-        if (bi < P && bi != 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->start_ev, 0));  // after whatever preceded this render
         rc = reset_counters(c, pp);
         if (rc != RTX_OK) return rc;
         launch_raygen(c->ds, pp.fr, info, lc);
         rc = run_path(c, pp, lc, levels, timing, ev_per_batch * bi);
         if (rc != RTX_OK) return rc;
-        // sums are folded in sample order (world.rs:54-61): accumulate follows the previous batch's
-        if (bi > 0) HIP_TRY(c, hipStreamWaitEvent(pp.main, c->chain[bi - 1], 0));
-        launch_accumulate(c->ds, pp.fr, info, c->sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
-        HIP_TRY(c, hipMemcpyAsync(c->h_counters + bi * CTR_WORDS, pp.fr.counters, CTR_WORDS * sizeof(uint32_t),
+        // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream
+        launch_accumulate(c->ds, pp.fr, info, pp.sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
+        HIP_TRY(c, hipMemcpyAsync(pp.h_counters + bi * CTR_WORDS, pp.fr.counters, CTR_WORDS * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, pp.main));
-        HIP_TRY(c, hipEventRecord(c->chain[bi], pp.main));
     }
-    if ((batches.size() - 1) % P != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->chain[batches.size() - 1], 0));
     HIP_TRY(c, hipGetLastError());
     if (!stats && d_tiles_out) {  // asynchronous device render: rtx_synchronize looks at the overflow flags
-        c->pending_batches = (uint32_t)batches.size();
+        pp.pending_batches = (uint32_t)batches.size();
         return RTX_OK;
     }
-    c->pending_batches = 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    pp.pending_batches = 0;
+    HIP_TRY(c, hipStreamSynchronize(pp.main));
     bool overflow = false;
     for (size_t bi = 0; bi < batches.size(); bi++)
-        if (c->h_counters[bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
+        if (pp.h_counters[bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
     if (overflow) {
         c->err = "wavefront pool overflow (internal sizing error)";
         return RTX_ERR_CAPACITY;
@@ -445,7 +431,7 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
         }
         stats->primary_rays = levels ? valid * spp : 0;
         for (size_t bi = 0; bi < batches.size(); bi++) {
-            const uint32_t *h = c->h_counters + bi * CTR_WORDS;
+            const uint32_t *h = pp.h_counters + bi * CTR_WORDS;
             stats->bounce_rays += (uint64_t)h[CTR_BOUNCE_LO] | ((uint64_t)h[CTR_BOUNCE_HI] << 32);
             stats->shadow_rays += (uint64_t)h[CTR_SHADOW_LO] | ((uint64_t)h[CTR_SHADOW_HI] << 32);
             stats->closest_nodes += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
@@ -461,17 +447,26 @@ int render_impl(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const
                              (unsigned long long)u[3], (unsigned long long)u[4], (unsigned long long)u[5],
                              (unsigned long long)u[6], (unsigned long long)u[7], (unsigned long long)u[8],
                              (unsigned long long)u[9]);
+                {
+                    uint32_t dbg[256];
+                    if (pp.allocs.size() && hipMemcpy(dbg, pp.fr.counters + CTR_WORDS, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+                        std::fprintf(stderr, "util stragglers (> 0.6 ms after the queue ran dry): %u\n", dbg[0]);
+                        for (uint32_t k = 0; k < std::min(dbg[0], 40u); k++)
+                            std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry\n",
+                                         dbg[1 + 6 * k] * 1e-5, dbg[2 + 6 * k], dbg[3 + 6 * k], dbg[4 + 6 * k], dbg[6 + 6 * k], dbg[5 + 6 * k]);
+                    }
+                }
                 std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms, mean / max time after the queue ran dry %.3f / %.3f ms\n",
                              (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
                              (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
             }
             float ms = 0;
             const size_t e = ev_per_batch * bi;
-            if (levels && hipEventElapsedTime(&ms, c->events[e], c->events[e + 1]) == hipSuccess) {
+            if (levels && hipEventElapsedTime(&ms, pp.events[e], pp.events[e + 1]) == hipSuccess) {
                 stats->path_kernel_ms += ms;
                 stats->path_launches++;
             }
-            if (hipEventElapsedTime(&ms, c->events[e + 1], c->events[e + 2]) == hipSuccess) stats->resolve_ms += ms;
+            if (hipEventElapsedTime(&ms, pp.events[e + 1], pp.events[e + 2]) == hipSuccess) stats->resolve_ms += ms;
         }
     }
     return RTX_OK;
@@ -505,7 +500,7 @@ int rtx_init(int device, rtx_ctx **out) {
     int n_pipes = 2;
     if (const char *np = std::getenv("RTX_PIPES")) n_pipes = std::min(4, std::max(1, std::atoi(np)));
     c->pipes.resize((size_t)n_pipes);
-    e = hipEventCreateWithFlags(&c->start_ev, hipEventDisableTiming);
+    e = hipSuccess;
     for (auto &pp : c->pipes)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp.main, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -526,8 +521,6 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
-    if (const char *ov = std::getenv("RTX_CONCURRENT"))  // 0: every batch on one stream
-        c->use_pipes = std::atoi(ov) != 0;
     if (const char *mn = std::getenv("RTX_MIN_BATCHES")) c->min_batches = (uint32_t)std::min(64, std::max(1, std::atoi(mn)));
     if (const char *mb = std::getenv("RTX_NODE_BUDGET_MB")) {
         long v = std::atol(mb);
@@ -545,15 +538,13 @@ void rtx_destroy(rtx_ctx *c) {
     free_all(c->scene_allocs);
     for (auto &pp : c->pipes) {
         free_all(pp.allocs);
+        if (pp.sum) (void)hipFree(pp.sum);
+        if (pp.h_counters) (void)hipHostFree(pp.h_counters);
+        for (auto e : pp.events) (void)hipEventDestroy(e);
         if (pp.main) (void)hipStreamDestroy(pp.main);
     }
-    if (c->sum) (void)hipFree(c->sum);
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->tiles_f32) (void)hipFree(c->tiles_f32);
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    for (auto e : c->events) (void)hipEventDestroy(e);
-    for (auto e : c->chain) (void)hipEventDestroy(e);
-    if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     delete c;
 }
 
@@ -677,14 +668,13 @@ uint64_t rtx_partition_pixels(rtx_ctx *c, const rtx_partition *part) {
 
 void *rtx_stream(rtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int rtx_synchronize(rtx_ctx *c) {
-    if (!c) return RTX_ERR_INVALID;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // an asynchronous rtx_render_device returned before its counters were back: report its overflow here
+static int sync_slot(rtx_ctx *c, Pipe &pp) {
+    HIP_TRY(c, hipStreamSynchronize(pp.main));
+    // an asynchronous render returned before its counters were back: its overflow is reported here
     bool overflow = false;
-    for (uint32_t bi = 0; bi < c->pending_batches && bi < c->h_counter_slots; bi++)
-        if (c->h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
-    c->pending_batches = 0;
+    for (uint32_t bi = 0; bi < pp.pending_batches && bi < pp.h_counter_slots; bi++)
+        if (pp.h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
+    pp.pending_batches = 0;
     if (overflow) {
         c->err = "wavefront pool overflow in the last asynchronous render (internal sizing error)";
         return RTX_ERR_CAPACITY;
@@ -692,11 +682,37 @@ int rtx_synchronize(rtx_ctx *c) {
     return RTX_OK;
 }
 
+int rtx_synchronize(rtx_ctx *c) {
+    if (!c) return RTX_ERR_INVALID;
+    int result = RTX_OK;
+    for (auto &pp : c->pipes) {
+        int rc = sync_slot(c, pp);
+        if (rc != RTX_OK) result = rc;
+    }
+    return result;
+}
+
+int rtx_slot_count(rtx_ctx *c) { return c ? (int)c->pipes.size() : RTX_ERR_INVALID; }
+
+void *rtx_slot_stream(rtx_ctx *c, uint32_t slot) { return c && slot < c->pipes.size() ? (void *)c->pipes[slot].main : nullptr; }
+
+int rtx_slot_synchronize(rtx_ctx *c, uint32_t slot) {
+    if (!c || slot >= c->pipes.size()) return RTX_ERR_INVALID;
+    return sync_slot(c, c->pipes[slot]);
+}
+
+int rtx_render_device_slot(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
+                           uint32_t flags, void *d_tiles, rtx_stats *stats) {
+    if (!c || !d_tiles) return RTX_ERR_INVALID;
+    Partition pt;
+    return render_impl(c, slot, spp, bounces, seed, part, flags, d_tiles, false, stats, pt);
+}
+
 int rtx_render_device(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
                       uint32_t flags, void *d_tiles, rtx_stats *stats) {
     if (!c || !d_tiles) return RTX_ERR_INVALID;
     Partition pt;
-    return render_impl(c, spp, bounces, seed, part, flags, d_tiles, false, stats, pt);
+    return render_impl(c, 0, spp, bounces, seed, part, flags, d_tiles, false, stats, pt);
 }
 
 int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
@@ -774,7 +790,7 @@ int rtx_render(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const 
     if (!c || !out_rgb8) return RTX_ERR_INVALID;
     Partition pt;
     rtx_stats local;
-    int rc = render_impl(c, spp, bounces, seed, part, flags, nullptr, out_f32 != nullptr, stats ? stats : &local, pt);
+    int rc = render_impl(c, 0, spp, bounces, seed, part, flags, nullptr, out_f32 != nullptr, stats ? stats : &local, pt);
     if (rc != RTX_OK) return rc;
     std::vector<uint8_t> h8(pt.npix * 3);
     HIP_TRY(c, hipMemcpy(h8.data(), c->tiles, h8.size(), hipMemcpyDeviceToHost));

@@ -372,26 +372,42 @@ def test_sample_batching_is_exact(rt, gpu, monkeypatch):
         c2.close()
 
 
-def test_concurrent_and_serial_schedules_agree(rt, gpu, monkeypatch):
-    """Batches alternating between two pipes (concurrent streams) and one batch on one stream must
-    not differ in a byte."""
+def test_slots_overlap_and_agree(rt, gpu, monkeypatch):
+    """Frames in flight in two render slots at once (different batchings, too) must not differ in a byte
+    from one frame rendered alone."""
     s = rt.HostScene("scan_glass", 512, 30000)
-    imgs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RTX_CONCURRENT", mode)
-        monkeypatch.setenv("RTX_PIPES", "2")
-        monkeypatch.setenv("RTX_MIN_BATCHES", "3" if mode == "1" else "1")
-        c = rt.Context(0)
-        try:
-            c.upload(s)
-            img, st = c.render(spp=8, bounces=4, seed=5)
-            img1, st1 = c.render(spp=1, bounces=4)       # pixel-range batches
-            imgs.append((img, img1, st.rays, st1.rays, st.batches))
-        finally:
-            c.close()
-    assert np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][1], imgs[1][1])
-    assert imgs[0][2:4] == imgs[1][2:4]
-    assert imgs[1][4] >= 2 and imgs[0][4] == 1
+    monkeypatch.setenv("RTX_MIN_BATCHES", "3")
+    c = rt.Context(0)
+    try:
+        c.upload(s)
+        assert c.slots >= 2
+        n = c.partition_pixels(None) * 3
+        ref = rt.DeviceBuffer(n)
+        st0 = c.render_device(ref.ptr, 8, 4, seed=5)               # alone, synchronous
+        assert st0.batches >= 3
+        bufs = [rt.DeviceBuffer(n, fill=k + 1) for k in range(4)]
+        for k, b in enumerate(bufs):                                # four frames queued without waiting, two slots
+            c.render_device(b.ptr, 8, 4, seed=5, stats=False, slot=k & 1)
+        c.synchronize()
+        want = ref.to_host()
+        assert want.any()
+        for k, b in enumerate(bufs):
+            got = b.to_host()
+            assert np.array_equal(got, want), f"frame {k} (slot {k & 1}): {(got != want).sum()} bytes differ"
+        st1 = c.render_device(bufs[0].ptr, 8, 4, seed=5, slot=1)   # counters of a slot-1 render
+        assert st1.rays == st0.rays and st1.batches == st0.batches
+    finally:
+        c.close()
+    monkeypatch.setenv("RTX_MIN_BATCHES", "1")
+    c = rt.Context(0)
+    try:
+        c.upload(s)
+        one = rt.DeviceBuffer(n)
+        st = c.render_device(one.ptr, 8, 4, seed=5)
+        assert st.batches == 1 and st.rays == st0.rays
+        assert np.array_equal(one.to_host(), want)
+    finally:
+        c.close()
 
 
 def test_errors(rt, gpu):
