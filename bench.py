@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s on the 2.37 M-triangle scene, 1024^2, 16 spp, 4 bounces.
 
-One "step" = one full pass of the trace path (raygen -> closest/shadow traversal -> shading
--> resolve -> RGB8 tiles) over the frame, scene already resident in HBM.  With N > 1 ranks
-(one process per GPU, torch.distributed over RCCL) the frame is split into interleaved
-32x32 tiles, every rank traces its tiles against its own copy of the scene, and the
-finished RGB8 tiles are all-gathered; total work is fixed, so scaling is "strong".
+One "step" = one full pass of the trace path (raygen -> the persistent path kernel: closest-hit and
+shadow queries of every bounce level -> resolve -> RGB8 tiles) over the frame, scene already
+resident in HBM.  Consecutive steps alternate between the context's two render slots, so one frame's
+drain (a few long dependent rays) runs under the next frame's bulk; every step is a complete frame.
+With N > 1 ranks (one process per GPU, torch.distributed) the frame is split into interleaved
+32x32 tiles, every rank traces its tiles against its own copy of the scene, and the finished RGB8
+tiles are all-gathered over RCCL; total work is fixed, so scaling is "strong".
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints one JSON line on rank 0 (see DESIGN.md for the roofline / cpu_baseline definitions).
+Prints one JSON line on rank 0 (see DESIGN.md section 4 for the roofline / cpu_baseline definitions).
 """
 import argparse
 import importlib
@@ -22,10 +24,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; random whole-line gathers from a 151 MB table (L2 + Infinity
+# Cache) 7.4-7.9 TB/s.  The path kernel's reads are such gathers (one 128-byte node or 64-byte
+# primitive record per lane and step); which row bounds them depends on the scene's size.
+HBM_PEAK_GBS = 8000.0
+MALL_GATHER_PEAK_GBS = 7650.0
+MALL_BYTES = 256 << 20
 RAY_IO_BYTES = 40      # 32 B ray in + 8 B hit out
 NODE_BYTES = 128       # one wide node (two tree levels) = one 128-byte line
 PRIM_BYTES = 64
+README_BUILD_S = 27.0  # reference README.md:7, 4-core i5-6600K (other hardware)
 
 
 SCENE_TEXT = {
@@ -42,78 +50,115 @@ SCENE_TEXT = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="scan")
-    ap.add_argument("--tris", type=int, default=0, help="triangle count of the synthetic scene (0 = 2,374,525)")
+    ap.add_argument("--tris", type=int, default=0, help="triangle count of the synthetic scene (0 = the config's own)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--slots", type=int, default=0, help="render slots the steps alternate between (0: one at N = 1, where the kernel times are then those of launches that have the GPU to themselves, two at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-visits", action="store_true", help="skip the untimed pass of the verbatim bvh.rs traversal")
     ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
     ap.add_argument("--cpu-row-stride", type=int, default=1, help="oracle traces every n-th image row (1: the whole frame, ~10 s of CPU work)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
     if args.one_device:
         local_rank = 0
+    torch = dist = device = None
     if world > 1:
+        # torch first: its bundled HIP runtime has to initialise before the library's (/opt/rocm) does
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
 
     rt = importlib.import_module("rust-raytracer_amd")
+    tl = importlib.import_module("rust-raytracer_amd.tiles") if world > 1 else None
     ctx = rt.Context(local_rank)
     t0 = time.time()
     scene = rt.HostScene(args.scene, args.width, args.tris)
     t_scene = time.time() - t0
     info = ctx.upload(scene)
     part = (args.tile, rank, world)
-    tl = importlib.import_module("rust-raytracer_amd.tiles")
-    n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
-    assert ctx.partition_pixels(part) <= n_pad * args.tile * args.tile
-    tiles = torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device)
+    n_slots = max(1, min(args.slots or (1 if world == 1 else 2), ctx.slots))
+    npix = ctx.partition_pixels(part)
     frame = [None]
+    if world > 1:
+        n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
+        assert npix <= n_pad * args.tile * args.tile
+        tiles = [torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device) for _ in range(n_slots)]
+        ptrs = [t.data_ptr() for t in tiles]
+        # the library renders on its slots' streams, the gather runs on torch's: a slot's next frame may
+        # overwrite its tile buffer only after the gather of its previous frame has read it
+        lib_streams = [torch.cuda.ExternalStream(ctx.slot_stream(k), device=device) for k in range(n_slots)]
+    else:
+        tiles = [rt.DeviceBuffer(npix * 3) for _ in range(n_slots)]
+        ptrs = [t.ptr for t in tiles]
 
-    # the library renders on its own stream; the gather runs on torch's: order the next frame's
-    # writes to `tiles` after the previous frame's all-gather has read them (device-side wait)
-    lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device) if world > 1 else None
+    issued = [0]
+    stats = []
 
-    def step(flags=0):
-        if lib_stream is not None:
-            lib_stream.wait_stream(torch.cuda.current_stream(device))
-        st = ctx.render_device(tiles.data_ptr(), args.spp, args.bounces, seed=1, part=part, flags=flags)
+    def step(flags=0, keep=True):
+        slot = issued[0] % n_slots
+        if issued[0] >= n_slots:
+            st = ctx.slot_stats(slot)                 # the frame this slot rendered n_slots steps ago (waits for it only)
+            if keep:
+                stats.append(st)
+        if world > 1:
+            lib_streams[slot].wait_stream(torch.cuda.current_stream(device))
+        ctx.render_device(ptrs[slot], args.spp, args.bounces, seed=1, part=part, flags=flags, stats=False, slot=slot)
         if world > 1:  # the frame's one exchange step: RGB8 tiles over RCCL, then de-interleave
-            frame[0] = tl.gather_image(tiles, args.width, args.width, args.tile, rank, world, dist)
-        return st
+            torch.cuda.current_stream(device).wait_stream(lib_streams[slot])
+            frame[0] = tl.gather_image(tiles[slot], args.width, args.width, args.tile, rank, world, dist)
+        issued[0] += 1
+
+    def drain(keep=True):
+        for k in range(max(issued[0] - n_slots, 0), issued[0]):
+            st = ctx.slot_stats(k % n_slots)
+            if keep:
+                stats.append(st)
+        issued[0] = 0
 
     def fence():
-        torch.cuda.synchronize()
+        ctx.synchronize()
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    counted = step(rt.FLAG_COUNT_VISITS)  # untimed pass with visit counters on
+        step(keep=False)
+    drain(keep=False)
+    # untimed passes with the visit counters on: the shipped traversal, and bvh.rs:359-395 verbatim for orientation
+    ctx.render_device(ptrs[0], args.spp, args.bounces, seed=1, part=part, flags=rt.FLAG_COUNT_VISITS, stats=False)
+    counted = ctx.slot_stats(0)
+    ref_counted = None
+    if world == 1 and not args.no_reference_visits:
+        ctx.render_device(ptrs[0], args.spp, args.bounces, seed=1, part=part,
+                          flags=rt.FLAG_COUNT_VISITS | rt.FLAG_REFERENCE_TRAVERSAL, stats=False)
+        ref_counted = ctx.slot_stats(0)
     fence()
+    stats.clear()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    for _ in range(args.steps):
+        step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
+    assert len(stats) == args.steps, (len(stats), args.steps)
     rays_step = stats[-1].rays
     if world > 1:
         cdev = device if args.backend == "nccl" else torch.device("cpu")
@@ -129,13 +174,17 @@ def main():
         return
 
     if args.out:
-        img = frame[0] if world > 1 else tl.gather_image(tiles, args.width, args.width, args.tile, 0, 1)
-        rt.png_write(args.out, img.cpu().numpy())
+        if world > 1:
+            img = frame[0].cpu().numpy()
+        else:
+            img = rt.untile(tiles[(args.steps - 1) % n_slots].to_host(), args.width, args.width, args.tile)
+        rt.png_write(args.out, img)
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_step * args.steps / elapsed / 1e6
     # Dominant kernel of rank 0 = the persistent path kernel: ONE launch per batch traces every ray of
-    # every bounce level (closest-hit and shadow queries), timed with HIP events on the library's
-    # stream (rtx_stats.path_kernel_ms) inside the timed region.
+    # every bounce level (closest-hit and shadow queries), timed with HIP events on the slot's stream
+    # (rtx_stats.path_kernel_ms) inside the timed region.  With two slots the launches of consecutive
+    # steps overlap, so a launch's own duration is longer than the step time it accounts for.
     p_ms = sum(s.path_kernel_ms for s in stats)
     p_l = sum(s.path_launches for s in stats)
     r_ms = sum(s.resolve_ms for s in stats) / args.steps
@@ -147,23 +196,54 @@ def main():
     s_bytes = NODE_BYTES * counted.shadow_nodes + PRIM_BYTES * counted.shadow_prims + RAY_IO_BYTES * s_rays
     t_bytes, t_rays = c_bytes + s_bytes, c_rays + s_rays
     bytes_per_launch = t_bytes / max(launches_per_step, 1)
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
+    delivery = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # the bound: scenes that fit the Infinity Cache are bounded by its gather rate, larger ones by HBM
+    in_mall = info.device_bytes <= MALL_BYTES
+    peak = MALL_GATHER_PEAK_GBS if in_mall else HBM_PEAK_GBS
+    # measured fabric traffic of the kernel (rocprofv3 --pmc FETCH_SIZE, doubled as the guide prescribes), from
+    # the committed PMC summary -- valid only for the kernel sources it was measured on and for this workload
+    traffic, pmc_note, valu = None, "no PMC summary for this workload", None
+    ppath = os.path.join(ROOT, "profiles", "pmc.json")
+    wkey = f"{args.scene}:{args.tris}:{args.width}:{args.spp}:{args.bounces}:{world}"
+    if os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        w = pj.get("workloads", {}).get(wkey)
+        if w and w.get("kernel_hash") == rt.kernel_source_hash():
+            traffic = int(w["path_fetch_bytes_per_launch"])
+            valu = w.get("valu")
+            pmc_note = f"profiles/pmc.json ({w.get('source', '')})"
+        elif w:
+            pmc_note = "profiles/pmc.json is stale: kernel sources changed since it was measured"
+    if traffic is not None:
+        achieved = traffic / (avg_launch_ms * 1e-3) / 1e9
+        basis = "measured fabric reads behind L2 (PMC) per launch / launch time"
+    else:
+        achieved = min(delivery, peak)
+        basis = "algorithmic record bytes / launch time, capped at the peak (no valid PMC traffic)"
 
     def per_class(nbytes, rays, nodes, prims):
         return {"rays_per_step": int(rays), "algorithmic_bytes_per_step": int(nbytes), "bytes_per_ray": round(nbytes / max(rays, 1), 1),
                 "nodes_per_ray": round(nodes / max(rays, 1), 3), "prims_per_ray": round(prims / max(rays, 1), 3)}
 
     roofline = {"bound": "hbm", "kernel": "path_kernel (closest-hit + shadow queries of all bounce levels, one persistent launch per batch)",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(min(achieved / peak, 1.0), 5), "traffic": traffic,
+                "peak_is": ("random 128-byte gathers from L2 + Infinity Cache (scene %.0f MB <= 256 MB)" % (info.device_bytes / 2**20)) if in_mall
+                           else "HBM3E (scene %.0f MB > Infinity Cache)" % (info.device_bytes / 2**20),
+                "frac_basis": basis, "pmc": pmc_note,
+                "record_delivery_GBps": round(delivery, 2),   # algorithmic bytes / time: records come from LDS, L1, L2 too
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                "launches_per_step": launches_per_step, "resolve_ms_per_step": round(r_ms, 4), "rays_per_step": int(t_rays),
-                "bytes_per_ray": round(t_bytes / max(t_rays, 1), 1),
+                "launches_per_step": launches_per_step, "slots": n_slots, "resolve_ms_per_step": round(r_ms, 4),
+                "rays_per_step": int(t_rays), "bytes_per_ray": round(t_bytes / max(t_rays, 1), 1), "valu": valu,
                 "per_class": {"closest": per_class(c_bytes, c_rays, counted.closest_nodes, counted.closest_prims),
                               "shadow": per_class(s_bytes, s_rays, counted.shadow_nodes, counted.shadow_prims)}}
+    if ref_counted is not None:  # the reference's own traversal (both children, no pruning) on the same rays, 64-byte binary nodes
+        roofline["reference_traversal_visits"] = {
+            "closest": {"nodes_per_ray": round(ref_counted.closest_nodes / max(c_rays, 1), 2), "prims_per_ray": round(ref_counted.closest_prims / max(c_rays, 1), 2)},
+            "shadow": {"nodes_per_ray": round(ref_counted.shadow_nodes / max(s_rays, 1), 2), "prims_per_ray": round(ref_counted.shadow_prims / max(s_rays, 1), 2)},
+            "path_kernel_ms": round(ref_counted.path_kernel_ms, 2)}
 
     cpu = None
+    build = {"hip_backend_s": round(info.build_seconds, 3), "reference_README_s": README_BUILD_S}
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc  # the oracle, as the reported CPU baseline only
@@ -175,6 +255,13 @@ def main():
         cpu = {"value": round(cst.rays / cst.trace_seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                "sample": (f"every {ys}. row of the same" if ys > 1 else "one whole") + f" {args.width}x{args.width} {args.spp}-spp frame "
                          f"({cst.rays} rays in {cst.trace_seconds:.1f} s; oracle BVH build {cst.build_seconds:.1f} s extra)"}
+        build["oracle_s"] = round(cst.build_seconds, 3)
+        # the reference's own default: -t 4 (main.rs:45; README.md:7 quotes a 4-core run) on a quarter of the rows
+        ys4 = ys * 4
+        _, c4 = o.render(spp=args.spp, bounces=args.bounces, seed=1, threads=4, region=(0, args.width, 1, 0, args.width, ys4))
+        cpu["threads_4"] = {"value": round(c4.rays / c4.trace_seconds / 1e6, 3), "unit": "Mrays/s", "cores": 4,
+                            "sample": f"every {ys4}. row ({c4.rays} rays in {c4.trace_seconds:.1f} s)",
+                            "reference_README": "39 s for this frame incl. 27 s BVH build on a 4-core i5-6600K (README.md:7): about 6 Mrays/s"}
         o.close()
 
     scene_text = SCENE_TEXT.get(args.scene, args.scene)
@@ -190,11 +277,12 @@ def main():
            "config": {"workload": f"{args.scene}: {scene_text}, {info.n_objects} primitives, "
                                   f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
                       "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
+                      "frames_in_flight": n_slots,
                       "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
                       "bvh": {"internal_nodes": info.n_internal, "leaves": info.n_leaves, "depth": info.depth,
                               "build_s": round(info.build_seconds, 3), "flatten_s": round(info.flatten_seconds, 3),
                               "upload_s": round(info.upload_seconds, 3), "scene_gen_s": round(t_scene, 3),
-                              "device_MB": round(info.device_bytes / 2**20, 1)}},
+                              "device_MB": round(info.device_bytes / 2**20, 1), "build_comparison": build}},
            "mprimary_samples_per_s": round(args.width * args.width * args.spp * args.steps / elapsed / 1e6, 2),
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)

@@ -170,6 +170,9 @@ int rtx_render_device_slot(rtx_ctx *ctx, uint32_t slot, uint32_t spp, uint32_t m
                            void *d_tiles_rgb8, rtx_stats *stats_or_null);
 void *rtx_slot_stream(rtx_ctx *ctx, uint32_t slot);
 int rtx_slot_synchronize(rtx_ctx *ctx, uint32_t slot);
+/* Waits for the slot's last render and reports its counters and kernel times (what stats_or_null
+ * would have received, had the call not been asynchronous; trace_ms: enqueue to completion). */
+int rtx_slot_stats(rtx_ctx *ctx, uint32_t slot, rtx_stats *out);
 
 /* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result bytes as

@@ -104,6 +104,7 @@ def lib():
     L.rtx_slot_stream.argtypes = [vp, C.c_uint32]
     L.rtx_slot_stream.restype = vp
     L.rtx_slot_synchronize.argtypes = [vp, C.c_uint32]
+    L.rtx_slot_stats.argtypes = [vp, C.c_uint32, C.POINTER(Stats)]
     L.rtx_partition_pixels.argtypes = [vp, C.POINTER(Partition)]
     L.rtx_partition_pixels.restype = C.c_uint64
     L.rtx_stream.argtypes = [vp]
@@ -375,6 +376,12 @@ class Context:
     def slot_stream(self, slot):
         return int(lib().rtx_slot_stream(self._h, slot) or 0)
 
+    def slot_stats(self, slot):
+        """Waits for the slot's last render; its rtx_stats."""
+        st = Stats()
+        self._check(lib().rtx_slot_stats(self._h, slot, C.byref(st)))
+        return st
+
     def slot_synchronize(self, slot):
         self._check(lib().rtx_slot_synchronize(self._h, slot))
 
@@ -479,6 +486,23 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a PMC measurement belongs to (profiles/pmc.json; bench.py drops stale ones)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h", "device_types.h"):
+        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def untile(buf, width, height, tile=32):
+    """Packed tiles of a whole frame ([tile][row in tile][col in tile][rgb], what rtx_render_device writes for
+    part = (tile, 0, 1)) -> row-major (height, width, 3) image."""
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    a = np.asarray(buf, np.uint8)[:tx * ty * tile * tile * 3].reshape(ty, tx, tile, tile, 3)
+    return np.ascontiguousarray(a.transpose(0, 2, 1, 3, 4).reshape(ty * tile, tx * tile, 3)[:height, :width])
 
 
 def png_read(path):

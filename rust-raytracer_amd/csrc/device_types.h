@@ -94,6 +94,9 @@ struct LightRec {
     // Cone lights: cos of the cut-off angle, for the cheap pre-filter in front of the reference's
     // atan2 comparison (light.rs:113-116); 2 = always outside, -2 = never outside (cut-off >= pi).
     float cos_cut;
+    // Cone lights: cos of (cut-off - 8.01 degrees): inside that, the falloff's cone factor clamp((cut-off -
+    // angle) / 8, 0, 1) is exactly 1 (light.rs:65-77) and the atan2 behind it need not run; 2 = never.
+    float cos_full;
 };
 
 enum : uint32_t { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTIONAL = 2, LIGHT_CONE = 3 };  // light.rs:12-17

@@ -364,6 +364,8 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             else if (cut < 0.0f) l.cos_cut = 2.0f;        // angle >= 0 > cut: always outside
             else if (cut >= 3.14159265f) l.cos_cut = -2.0f;  // angle <= pi <= cut: never outside
             else l.cos_cut = (float)std::cos((double)cut);
+            const double full = (double)l.angle_deg - 8.01;  // degrees
+            l.cos_full = (full == full && full > 1.0 && full < 89.0) ? (float)std::cos(full * 3.14159265358979323846 / 180.0) : 2.0f;
         }
     }
     // primitives in leaf order

@@ -452,6 +452,13 @@ __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack
     st.sp = 0;
     uint32_t root = REF ? sc.root_ref : sc.wroot_ref;
     if (root == NO_PRIM) return;
+    if (!REF && !(root & LEAF_BIT)) {
+        // The reference tests the root's own box first (bvh.rs:362).  A ray that misses it misses every
+        // box inside it (see box_test), so the production traversal leaves that to the root node's slots
+        // and saves the test -- divisions and all -- at every ray start; a root LEAF keeps it (exact).
+        s.cur = root;
+        return;
+    }
     float te;
     // (no pruning of the root box in scenes whose hits can lie outside their boxes)
     if (box_test(sc.root_mn[0], sc.root_mn[1], sc.root_mn[2], sc.root_mx[0], sc.root_mx[1], sc.root_mx[2], s.r,
@@ -632,6 +639,9 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 #ifndef RTX_LEAF_WEIGHT
 #define RTX_LEAF_WEIGHT 1
 #endif
+#ifndef RTX_NODE_WEIGHT
+#define RTX_NODE_WEIGHT 1
+#endif
 // Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
 // tools/util_probe.py prints it): wave steps and executing lanes per kind.
 struct Util {
@@ -665,7 +675,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #ifdef RTX_UTIL_STATS
     u.done_lanes += 64u - nl - nn;
 #endif
-    if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn) {
+    if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn * (uint32_t)RTX_NODE_WEIGHT) {
 #ifdef RTX_UTIL_STATS
         u.prim_steps++;
         u.prim_lanes += nl;
@@ -1260,23 +1270,41 @@ __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_ovh_kernel(Devic
 }
 
 // ---------------------------------------------------------------- resolve
-// Light::get_falloff_at (light.rs:58-79)
+// Light::get_falloff_at (light.rs:58-79).  The cone factor is clamp((cut-off - angle) / 8 degrees, 0, 1): exactly
+// 1 for every point more than 8 degrees inside the cone, which the signed squared cosine settles
+// (cos_full carries 0.01 degrees of margin, a thousand times the rounding of either side); only
+// the rim runs the reference's atan2, behind a wave-uniform branch.
 __device__ __forceinline__ float falloff_at(const LightRec &L, F3 point) {
     F3 lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
     F3 dv = lpos - point;
     float d2 = dot(dv, dv);
     if (L.type == 1u) return 5.0f / (0.001f + d2);
-    float angle_to_point = angle_rad(f3(L.dir[0], L.dir[1], L.dir[2]), point - lpos) * RAD_TO_DEG;
-    float angle_delta = L.angle_deg - angle_to_point;
-    float cone = clampf(angle_delta / 8.0f, 0.0f, 1.0f);
+    const F3 a = f3(L.dir[0], L.dir[1], L.dir[2]), b = point - lpos;
+    const float dt = dot(a, b), l2 = dot(a, a) * dot(b, b);
+    const bool rim = !(dt > 0.0f && dt * dt > (L.cos_full * fabsf(L.cos_full)) * l2 && L.cos_full > 0.0f && L.cos_full <= 1.0f);
+    float cone = 1.0f;
+    if (__ballot(rim) != 0ull) {
+        if (rim) {
+            float angle_to_point = angle_rad(a, b) * RAD_TO_DEG;
+            float angle_delta = L.angle_deg - angle_to_point;
+            cone = clampf(angle_delta / 8.0f, 0.0f, 1.0f);
+        }
+    }
     return cone * 5.0f / (0.001f + d2);
 }
-// MaterialType::get_phong_multiple (material.rs:98-113)
+// MaterialType::get_phong_multiple (material.rs:98-113).  ks * spec^shininess is +0 without calling powf when
+// ks or spec is +0 and the exponent positive (powf of a number in [0, 1] is finite, powf(+0, y > 0) is +0).
 __device__ __forceinline__ float phong_multiple(F3 to_light, F3 normal, F3 incoming, float kd, float ks, float sh) {
     F3 rv = reflect(to_light, normal);
     float spec = clampf(-dot(rv, incoming), 0.0f, 1.0f);
     float diff = clampf(dot(to_light, normal), 0.0f, 1.0f);
-    return kd * diff + ks * powf(spec, sh);
+    const bool zero = sh > 0.0f && sh < INFINITY && ks >= 0.0f && ks < INFINITY && spec == spec &&
+                      (__float_as_uint(ks) == 0u || __float_as_uint(spec) == 0u);
+    float sp = 0.0f;
+    if (__ballot(!zero) != 0ull) {
+        if (!zero) sp = ks * powf(spec, sh);
+    }
+    return kd * diff + sp;
 }
 // TextureType::sample (material.rs:53-76)
 __device__ __forceinline__ F3 texture_sample(const DeviceScene &sc, const MaterialRec &m, const PrimView &pv, F3 p) {

@@ -40,6 +40,10 @@ struct Pipe {
     uint32_t h_counter_slots = 0;
     std::vector<hipEvent_t> events;   // timing (renders with stats)
     uint32_t pending_batches = 0;     // batches of the last asynchronous render whose overflow flags nobody has looked at
+    // the last render of this slot, for rtx_slot_stats
+    uint32_t last_batches = 0, last_levels = 0;
+    uint64_t last_primary = 0;
+    double last_t0 = 0;               // host time the render was enqueued at (synchronous renders: after the stream had drained)
 };
 
 struct rtx_ctx {
@@ -304,6 +308,67 @@ int run_path(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, s
     return RTX_OK;
 }
 
+constexpr size_t EV_PER_BATCH = 3;  // path begin, path end, resolves end
+
+// Waits for the slot's last render and reports it (overflow flags, counters, event times).
+int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
+    HIP_TRY(c, hipStreamSynchronize(pp.main));
+    const double t1 = now_s();
+    const uint32_t nb = std::min(pp.last_batches, pp.h_counter_slots);
+    bool overflow = false;
+    for (uint32_t bi = 0; bi < pp.pending_batches && bi < pp.h_counter_slots; bi++)
+        if (pp.h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
+    pp.pending_batches = 0;
+    if (overflow) {
+        c->err = "wavefront pool overflow (internal sizing error)";
+        return RTX_ERR_CAPACITY;
+    }
+    if (!stats) return RTX_OK;
+    std::memset(stats, 0, sizeof(*stats));
+    stats->trace_ms = (t1 - pp.last_t0) * 1e3;
+    stats->batches = nb;
+    stats->primary_rays = pp.last_primary;
+    for (size_t bi = 0; bi < nb; bi++) {
+        const uint32_t *h = pp.h_counters + bi * CTR_WORDS;
+        stats->bounce_rays += (uint64_t)h[CTR_BOUNCE_LO] | ((uint64_t)h[CTR_BOUNCE_HI] << 32);
+        stats->shadow_rays += (uint64_t)h[CTR_SHADOW_LO] | ((uint64_t)h[CTR_SHADOW_HI] << 32);
+        stats->closest_nodes += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
+        stats->closest_prims += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
+        stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
+        stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
+        stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
+        if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
+            const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
+            std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu "
+                                 "events %llu shade_events %llu shade_lanes %llu start_lanes %llu fin_lanes %llu\n",
+                         (unsigned long long)u[0], (unsigned long long)u[1], (unsigned long long)u[2],
+                         (unsigned long long)u[3], (unsigned long long)u[4], (unsigned long long)u[5],
+                         (unsigned long long)u[6], (unsigned long long)u[7], (unsigned long long)u[8],
+                         (unsigned long long)u[9]);
+            uint32_t dbg[256];
+            if (pp.allocs.size() && hipMemcpy(dbg, pp.fr.counters + CTR_WORDS, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+                std::fprintf(stderr, "util stragglers (> 0.6 ms after the queue ran dry): %u\n", dbg[0]);
+                for (uint32_t k = 0; k < std::min(dbg[0], 40u); k++)
+                    std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry\n",
+                                 dbg[1 + 6 * k] * 1e-5, dbg[2 + 6 * k], dbg[3 + 6 * k], dbg[4 + 6 * k], dbg[6 + 6 * k], dbg[5 + 6 * k]);
+            }
+            std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms, mean / max time after the queue ran dry %.3f / %.3f ms\n",
+                         (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
+                         (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
+        }
+        float ms = 0;
+        const size_t e = EV_PER_BATCH * bi;
+        if (e + 2 < pp.events.size()) {
+            if (pp.last_levels && hipEventElapsedTime(&ms, pp.events[e], pp.events[e + 1]) == hipSuccess) {
+                stats->path_kernel_ms += ms;
+                stats->path_launches++;
+            }
+            if (hipEventElapsedTime(&ms, pp.events[e + 1], pp.events[e + 2]) == hipSuccess) stats->resolve_ms += ms;
+        }
+    }
+    return RTX_OK;
+}
+
 int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
                 uint32_t flags, void *d_tiles_out, bool want_f32, rtx_stats *stats, Partition &pt) {
     if (!c->has_scene) {
@@ -361,20 +426,16 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     if (rc != RTX_OK) return rc;
     rc = ensure_counter_slots(c, pp, (uint32_t)batches.size());
     if (rc != RTX_OK) return rc;
-    bool timing = stats != nullptr;
-    const size_t ev_per_batch = 3;  // path begin, path end, resolves end
-    if (timing) {
-        rc = ensure_events(c, pp, ev_per_batch * batches.size());
-        if (rc != RTX_OK) return rc;
-    }
+    const bool timing = true;  // three event records per batch cost nothing; rtx_slot_stats reads them later
+    const size_t ev_per_batch = EV_PER_BATCH;
+    rc = ensure_events(c, pp, ev_per_batch * batches.size());
+    if (rc != RTX_OK) return rc;
     LaunchCfg lc{pp.main, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
                  (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
     uint8_t *tiles = d_tiles_out ? static_cast<uint8_t *>(d_tiles_out) : c->tiles;
-    double t0 = 0;
-    if (timing) {
-        HIP_TRY(c, hipStreamSynchronize(pp.main));
-        t0 = now_s();
-    }
+    const bool async = !stats && d_tiles_out;
+    if (!async) HIP_TRY(c, hipStreamSynchronize(pp.main));
+    pp.last_t0 = now_s();
     for (size_t bi = 0; bi < batches.size(); bi++) {
         const Batch &b = batches[bi];
         BatchInfo info{};
@@ -403,73 +464,21 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
                                   hipMemcpyDeviceToHost, pp.main));
     }
     HIP_TRY(c, hipGetLastError());
-    if (!stats && d_tiles_out) {  // asynchronous device render: rtx_synchronize looks at the overflow flags
-        pp.pending_batches = (uint32_t)batches.size();
-        return RTX_OK;
+    // valid primary samples of this rank
+    uint64_t valid = 0;
+    for (uint32_t lt = 0; lt < pt.my_tiles; lt++) {
+        uint64_t gt = (uint64_t)lt * pt.nranks + pt.rank;
+        uint32_t tx = (uint32_t)(gt % pt.tiles_x), ty = (uint32_t)(gt / pt.tiles_x);
+        uint32_t w = std::min(pt.tile, c->ds.width - std::min(c->ds.width, tx * pt.tile));
+        uint32_t h = std::min(pt.tile, c->ds.height - std::min(c->ds.height, ty * pt.tile));
+        valid += (uint64_t)w * h;
     }
-    pp.pending_batches = 0;
-    HIP_TRY(c, hipStreamSynchronize(pp.main));
-    bool overflow = false;
-    for (size_t bi = 0; bi < batches.size(); bi++)
-        if (pp.h_counters[bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
-    if (overflow) {
-        c->err = "wavefront pool overflow (internal sizing error)";
-        return RTX_ERR_CAPACITY;
-    }
-    if (stats) {
-        std::memset(stats, 0, sizeof(*stats));
-        stats->trace_ms = (now_s() - t0) * 1e3;
-        stats->batches = (uint32_t)batches.size();
-        // valid primary samples of this rank
-        uint64_t valid = 0;
-        for (uint32_t lt = 0; lt < pt.my_tiles; lt++) {
-            uint64_t gt = (uint64_t)lt * pt.nranks + pt.rank;
-            uint32_t tx = (uint32_t)(gt % pt.tiles_x), ty = (uint32_t)(gt / pt.tiles_x);
-            uint32_t w = std::min(pt.tile, c->ds.width - std::min(c->ds.width, tx * pt.tile));
-            uint32_t h = std::min(pt.tile, c->ds.height - std::min(c->ds.height, ty * pt.tile));
-            valid += (uint64_t)w * h;
-        }
-        stats->primary_rays = levels ? valid * spp : 0;
-        for (size_t bi = 0; bi < batches.size(); bi++) {
-            const uint32_t *h = pp.h_counters + bi * CTR_WORDS;
-            stats->bounce_rays += (uint64_t)h[CTR_BOUNCE_LO] | ((uint64_t)h[CTR_BOUNCE_HI] << 32);
-            stats->shadow_rays += (uint64_t)h[CTR_SHADOW_LO] | ((uint64_t)h[CTR_SHADOW_HI] << 32);
-            stats->closest_nodes += (uint64_t)h[CTR_VISIT_NODES_LO] | ((uint64_t)h[CTR_VISIT_NODES_HI] << 32);
-            stats->closest_prims += (uint64_t)h[CTR_VISIT_PRIMS_LO] | ((uint64_t)h[CTR_VISIT_PRIMS_HI] << 32);
-            stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
-            stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
-            stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
-            if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
-                const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
-                std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu "
-                                     "events %llu shade_events %llu shade_lanes %llu start_lanes %llu fin_lanes %llu\n",
-                             (unsigned long long)u[0], (unsigned long long)u[1], (unsigned long long)u[2],
-                             (unsigned long long)u[3], (unsigned long long)u[4], (unsigned long long)u[5],
-                             (unsigned long long)u[6], (unsigned long long)u[7], (unsigned long long)u[8],
-                             (unsigned long long)u[9]);
-                {
-                    uint32_t dbg[256];
-                    if (pp.allocs.size() && hipMemcpy(dbg, pp.fr.counters + CTR_WORDS, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
-                        std::fprintf(stderr, "util stragglers (> 0.6 ms after the queue ran dry): %u\n", dbg[0]);
-                        for (uint32_t k = 0; k < std::min(dbg[0], 40u); k++)
-                            std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry\n",
-                                         dbg[1 + 6 * k] * 1e-5, dbg[2 + 6 * k], dbg[3 + 6 * k], dbg[4 + 6 * k], dbg[6 + 6 * k], dbg[5 + 6 * k]);
-                    }
-                }
-                std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms, mean / max time after the queue ran dry %.3f / %.3f ms\n",
-                             (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
-                             (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
-            }
-            float ms = 0;
-            const size_t e = ev_per_batch * bi;
-            if (levels && hipEventElapsedTime(&ms, pp.events[e], pp.events[e + 1]) == hipSuccess) {
-                stats->path_kernel_ms += ms;
-                stats->path_launches++;
-            }
-            if (hipEventElapsedTime(&ms, pp.events[e + 1], pp.events[e + 2]) == hipSuccess) stats->resolve_ms += ms;
-        }
-    }
-    return RTX_OK;
+    pp.last_batches = (uint32_t)batches.size();
+    pp.last_levels = levels;
+    pp.last_primary = levels ? valid * spp : 0;
+    pp.pending_batches = (uint32_t)batches.size();
+    if (async) return RTX_OK;  // rtx_synchronize / rtx_slot_stats look at the overflow flags
+    return slot_stats(c, pp, stats);
 }
 
 }  // namespace
@@ -668,19 +677,7 @@ uint64_t rtx_partition_pixels(rtx_ctx *c, const rtx_partition *part) {
 
 void *rtx_stream(rtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-static int sync_slot(rtx_ctx *c, Pipe &pp) {
-    HIP_TRY(c, hipStreamSynchronize(pp.main));
-    // an asynchronous render returned before its counters were back: its overflow is reported here
-    bool overflow = false;
-    for (uint32_t bi = 0; bi < pp.pending_batches && bi < pp.h_counter_slots; bi++)
-        if (pp.h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
-    pp.pending_batches = 0;
-    if (overflow) {
-        c->err = "wavefront pool overflow in the last asynchronous render (internal sizing error)";
-        return RTX_ERR_CAPACITY;
-    }
-    return RTX_OK;
-}
+static int sync_slot(rtx_ctx *c, Pipe &pp) { return slot_stats(c, pp, nullptr); }
 
 int rtx_synchronize(rtx_ctx *c) {
     if (!c) return RTX_ERR_INVALID;
@@ -699,6 +696,11 @@ void *rtx_slot_stream(rtx_ctx *c, uint32_t slot) { return c && slot < c->pipes.s
 int rtx_slot_synchronize(rtx_ctx *c, uint32_t slot) {
     if (!c || slot >= c->pipes.size()) return RTX_ERR_INVALID;
     return sync_slot(c, c->pipes[slot]);
+}
+
+int rtx_slot_stats(rtx_ctx *c, uint32_t slot, rtx_stats *out) {
+    if (!c || !out || slot >= c->pipes.size()) return RTX_ERR_INVALID;
+    return slot_stats(c, c->pipes[slot], out);
 }
 
 int rtx_render_device_slot(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,

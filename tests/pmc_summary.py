@@ -29,17 +29,30 @@ for k in sorted(tot):
     if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]):
         print(f"   -> L2 hit rate = {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.4f}")
 
-# HBM-side traffic per launch for bench.py's roofline.traffic: FETCH_SIZE is in KB and, on gfx950,
-# tallies the L2's 128-byte fabric reads at 64 B (MI355X_MICROARCH.md, HBM section), hence the x2;
-# the TCC_EA0_RDREQ_{32,64,128}B breakdown of the same command confirms every request is 128 B.
+# Fabric traffic per launch and VALU issue share of the path kernel for bench.py's roofline object:
+# FETCH_SIZE is in KB and, on gfx950, tallies the L2's 128-byte fabric reads at 64 B (MI355X_MICROARCH.md,
+# HBM section), hence the x2.  Usage: pmc_summary.py <dir> <profiles/pmc.json> <workload key> <source note>
+import importlib
 import json
-traffic = {}
-for k in tot:
-    if "FETCH_SIZE" in tot[k] and ("trace_" in k):
-        n = len([1 for f, d in calls[k] if "tcc2" in f])
-        if n:
-            traffic[k] = {"fetch_bytes_per_launch": tot[k]["FETCH_SIZE"] * 1024 * 2 / n, "launches_profiled": n,
-                          "rdreq_128B": tot[k].get("TCC_EA0_RDREQ_128B_sum"), "rdreq_64B": tot[k].get("TCC_EA0_RDREQ_64B_sum"),
-                          "rdreq_32B": tot[k].get("TCC_EA0_RDREQ_32B_sum")}
-if len(sys.argv) > 2:
-    json.dump(traffic, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+if len(sys.argv) > 4:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    rt = importlib.import_module("rust-raytracer_amd")
+    out_path, wkey, note = sys.argv[2], sys.argv[3], sys.argv[4]
+    kname = [k for k in tot if k.startswith("path_kernel<false, false, true>") or k.startswith("path_ovh_kernel<false, true>")]
+    if kname:
+        k = kname[0]
+        c = tot[k]
+        n_fetch = len([1 for f, d_ in calls[k] if "tcc2" in f]) or 1
+        n_sq = len([1 for f, d_ in calls[k] if "sq1" in f]) or 1
+        entry = {"kernel": k, "kernel_hash": rt.kernel_source_hash(), "source": note,
+                 "path_fetch_bytes_per_launch": c.get("FETCH_SIZE", 0.0) * 1024 * 2 / n_fetch, "launches_profiled": n_fetch}
+        if c.get("SQ_INSTS_VALU") and c.get("SQ_WAVE_CYCLES"):
+            # SQ_WAVE_CYCLES counts 4-cycle quads per resident wave; a wave64 VALU instruction occupies its SIMD for 4 cycles,
+            # and 5 waves share a SIMD: issue share = VALU instructions / (wave quads / waves per SIMD)
+            entry["valu"] = {"insts_per_launch": c["SQ_INSTS_VALU"] / n_sq,
+                             "active_lane_fraction": c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),
+                             "issue_share_of_simd_time": c["SQ_INSTS_VALU"] / (c["SQ_WAVE_CYCLES"] / 5.0)}
+        pj = json.load(open(out_path)) if os.path.exists(out_path) else {"workloads": {}}
+        pj.setdefault("workloads", {})[wkey] = entry
+        json.dump(pj, open(out_path, "w"), indent=1, sort_keys=True)
+        print("wrote", out_path, wkey, entry)
