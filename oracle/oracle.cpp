@@ -539,15 +539,19 @@ namespace {
 
 struct Counters {
     uint64_t primary = 0, bounce = 0, shadow = 0;
+    // visits of the traversal below (bvh.rs:359-395), split by who asked: [0] internal nodes entered
+    // (own box hit), [1] objects tested (leaf sizes of the leaves whose box was hit)
+    uint64_t closest_vis[2] = {0, 0}, shadow_vis[2] = {0, 0};
 };
 
 // bvh.rs:359-395
-bool bvh_closest(const orc_scene &s, const BvhTree *n, const Ray &ray, Hit *out) {
+bool bvh_closest(const orc_scene &s, const BvhTree *n, const Ray &ray, Hit *out, uint64_t *vis) {
     if (!aabb_intersect(n->aabb, ray, nullptr)) return false;
     if (!n->leaf) {
+        if (vis) vis[0]++;
         Hit hl, hr;
-        bool bl = bvh_closest(s, n->left.get(), ray, &hl);
-        bool br = bvh_closest(s, n->right.get(), ray, &hr);
+        bool bl = bvh_closest(s, n->left.get(), ray, &hl, vis);
+        bool br = bvh_closest(s, n->right.get(), ray, &hr, vis);
         if (bl && br) {
             *out = (hl.t > hr.t) ? hr : hl;  // min_by keeps the first unless Greater
             return true;
@@ -564,6 +568,7 @@ bool bvh_closest(const orc_scene &s, const BvhTree *n, const Ray &ray, Hit *out)
     }
     bool any = false;
     Hit best{0, 0};
+    if (vis) vis[1] += n->objects.size();
     for (uint32_t oi : n->objects) {
         float t;
         if (object_intersect(s.objects[oi], ray, &t)) {
@@ -579,8 +584,8 @@ bool bvh_closest(const orc_scene &s, const BvhTree *n, const Ray &ray, Hit *out)
     return any;
 }
 // bvh.rs:33-35
-inline bool get_closest_intersection(const orc_scene &s, const Ray &ray, Hit *out) {
-    return bvh_closest(s, s.bvh.get(), ray, out);
+inline bool get_closest_intersection(const orc_scene &s, const Ray &ray, Hit *out, uint64_t *vis = nullptr) {
+    return bvh_closest(s, s.bvh.get(), ray, out, vis);
 }
 
 // light.rs:81-97
@@ -589,7 +594,7 @@ bool in_shadow(const orc_scene &s, V3 point, V3 light_position, V3 light_directi
     float light_to_point_t = magnitude(light_position - point);
     c.shadow++;
     Hit h;
-    if (get_closest_intersection(s, light_ray, &h)) {
+    if (get_closest_intersection(s, light_ray, &h, c.shadow_vis)) {
         float epsilon = 1e-4f;
         bool is_in_shadow = h.t + epsilon < light_to_point_t;
         return !is_in_shadow;
@@ -605,7 +610,7 @@ bool reaches_point(const orc_scene &s, const Light &l, V3 point, Counters &c) {
             Ray r = Ray::make(point, -l.dir).offset(1e-4f);
             c.shadow++;
             Hit h;
-            return !get_closest_intersection(s, r, &h);
+            return !get_closest_intersection(s, r, &h, c.shadow_vis);
         }
         default: {
             V3 light_direction = point - l.pos;
@@ -718,7 +723,7 @@ Color trace_ray(const orc_scene &s, const Ray &ray, uint32_t max_depth, bool pri
     if (primary) c.primary++;
     else c.bounce++;
     Hit h;
-    if (!get_closest_intersection(s, ray, &h)) return s.background;
+    if (!get_closest_intersection(s, ray, &h, c.closest_vis)) return s.background;
     const Object &o = s.objects[h.obj];
     V3 p = ray.get_point_on_ray(h.t);
     std::vector<const Light *> lit;
@@ -899,6 +904,10 @@ int orc_render(orc_scene *s, uint32_t spp, uint32_t bounces, uint64_t seed, int 
             stats->primary_rays += c.primary;
             stats->bounce_rays += c.bounce;
             stats->shadow_rays += c.shadow;
+            stats->closest_nodes += c.closest_vis[0];
+            stats->closest_prims += c.closest_vis[1];
+            stats->shadow_nodes += c.shadow_vis[0];
+            stats->shadow_prims += c.shadow_vis[1];
         }
         stats->build_seconds = s->build_seconds;
         stats->trace_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

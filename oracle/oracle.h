@@ -64,6 +64,10 @@ typedef struct orc_scene orc_scene;
 typedef struct orc_stats {
     uint64_t primary_rays, bounce_rays, shadow_rays;  /* one ray = one Bvh::get_closest_intersection */
     double build_seconds, trace_seconds;
+    /* visits of BvhTree::get_closest_intersection (bvh.rs:359-395) over those rays: internal nodes whose own
+     * box the ray passes, and objects tested (the Vec of every leaf whose box the ray passes); closest = the
+     * queries of World::trace_ray (world.rs:118), shadow = those of Light::reaches_point (light.rs:90,111) */
+    uint64_t closest_nodes, closest_prims, shadow_nodes, shadow_prims;
 } orc_stats;
 
 orc_scene *orc_scene_create(const orc_scene_desc *desc);

@@ -13,7 +13,9 @@ _f32p, _u8p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_u
 
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("build_seconds", C.c_double), ("trace_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("trace_seconds", C.c_double),
+                ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64), ("shadow_nodes", C.c_uint64),
+                ("shadow_prims", C.c_uint64)]
 
     @property
     def rays(self):

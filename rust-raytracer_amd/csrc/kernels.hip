@@ -623,8 +623,10 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
             s.any = true;
             if (tw + 1e-4f < dist) {
                 s.occluded = true;
-                s.cur = TRAV_DONE;
-                return;
+                if (!REF) {  // (the verbatim traversal goes on: the reference asks for the closest hit, light.rs:90)
+                    s.cur = TRAV_DONE;
+                    return;
+                }
             }
             if (!REF) s.limit_plus = dist + (s.r.slack0 + 1.5e-5f * fabsf(dist));
         }

@@ -79,6 +79,30 @@ def test_visit_counters(rt, gpu):
     assert st1.rays == st0.rays == st2.rays
 
 
+@pytest.mark.parametrize("name,width,param", [("basic_suzanne", 96, 0), ("scan", 96, 20000), ("random_spheres", 64, 300)])
+def test_visit_counters_match_the_oracle(rt, orc, gpu, name, width, param):
+    """The counters behind the roofline's byte count: the device's verbatim traversal (RTX_FLAG_REFERENCE_TRAVERSAL |
+    RTX_FLAG_COUNT_VISITS) must visit exactly the nodes and objects that the oracle's bvh.rs:359-395 restatement
+    counts on the same rays.  Closest-hit queries are bit-identical rays: exact.  Shadow queries: exact whenever both
+    sides ask the same number of them (a cone cut-off decided by atan2's last ulp can add or drop a query)."""
+    s, o = _pair(rt, orc, gpu, name, width, param)
+    _, st_o = o.render(spp=2, bounces=3, seed=4)
+    _, st_g = gpu.render(spp=2, bounces=3, seed=4, flags=rt.FLAG_COUNT_VISITS | rt.FLAG_REFERENCE_TRAVERSAL)
+    assert st_o.closest_nodes > 0 and st_o.closest_prims > 0
+    assert (st_g.primary_rays, st_g.bounce_rays) == (st_o.primary_rays, st_o.bounce_rays)
+    assert (st_g.closest_nodes, st_g.closest_prims) == (st_o.closest_nodes, st_o.closest_prims)
+    if st_g.shadow_rays == st_o.shadow_rays:
+        assert (st_g.shadow_nodes, st_g.shadow_prims) == (st_o.shadow_nodes, st_o.shadow_prims)
+    else:
+        assert abs(st_g.shadow_rays - st_o.shadow_rays) <= 1e-4 * st_o.shadow_rays
+        assert abs(st_g.shadow_nodes - st_o.shadow_nodes) <= 1e-3 * st_o.shadow_nodes
+        assert abs(st_g.shadow_prims - st_o.shadow_prims) <= 1e-3 * st_o.shadow_prims
+    # the shipped traversal finds the same hits with fewer visits
+    _, st_p = gpu.render(spp=2, bounces=3, seed=4, flags=rt.FLAG_COUNT_VISITS)
+    assert st_p.rays == st_g.rays
+    assert 0 < st_p.closest_prims <= st_g.closest_prims and 0 < st_p.shadow_prims <= st_g.shadow_prims
+
+
 def test_bounce_depths(rt, orc, gpu):
     s, o = _pair(rt, orc, gpu, "basic", 64, 0)
     for b in (0, 1, 2, 6):
