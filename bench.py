@@ -63,7 +63,10 @@ def main():
     ap.add_argument("--no-reference-visits", action="store_true", help="skip the untimed pass of the verbatim bvh.rs traversal")
     ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
     ap.add_argument("--cpu-row-stride", type=int, default=1, help="oracle traces every n-th image row (1: the whole frame, ~10 s of CPU work)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: rccl = the library's own communicator (rtx_comm_init / rtx_gather_image; torch.distributed over gloo only "
+                         "hands out the RCCL id and synchronises the clocks), torch = torch.distributed all_gather_into_tensor")
+    ap.add_argument("--backend", default="nccl", help="--gather torch: torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
@@ -73,21 +76,30 @@ def main():
     if args.one_device:
         local_rank = 0
     torch = dist = device = None
+    lib_gather = world > 1 and args.gather == "rccl"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
-        # torch first: its bundled HIP runtime has to initialise before the library's (/opt/rocm) does
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        device = torch.device("cuda", local_rank)
-        torch.cuda.set_device(device)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+        if lib_gather:
+            dist.init_process_group("gloo")   # host-side rendezvous only: the GPU never sees torch
         else:
-            dist.init_process_group(args.backend)
+            # torch first: its bundled HIP runtime has to initialise before the library's (/opt/rocm) does
+            device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(args.backend)
 
     rt = importlib.import_module("rust-raytracer_amd")
-    tl = importlib.import_module("rust-raytracer_amd.tiles") if world > 1 else None
+    tl = importlib.import_module("rust-raytracer_amd.tiles") if world > 1 and not lib_gather else None
     ctx = rt.Context(local_rank)
+    if lib_gather:
+        ids = [rt.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
     t0 = time.time()
     scene = rt.HostScene(args.scene, args.width, args.tris)
     t_scene = time.time() - t0
@@ -96,7 +108,13 @@ def main():
     n_slots = max(1, min(args.slots or (1 if world == 1 else 2), ctx.slots))
     npix = ctx.partition_pixels(part)
     frame = [None]
-    if world > 1:
+    if lib_gather:
+        nbytes = ctx.gather_bytes_per_rank(args.tile)
+        tiles = [rt.DeviceBuffer(nbytes) for _ in range(n_slots)]
+        ptrs = [t.ptr for t in tiles]
+        all_tiles = [rt.DeviceBuffer(nbytes * world) for _ in range(n_slots)]
+        images = [rt.DeviceBuffer(args.width * args.width * 3) for _ in range(n_slots)]
+    elif world > 1:
         n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
         assert npix <= n_pad * args.tile * args.tile
         tiles = [torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device) for _ in range(n_slots)]
@@ -117,10 +135,12 @@ def main():
             st = ctx.slot_stats(slot)                 # the frame this slot rendered n_slots steps ago (waits for it only)
             if keep:
                 stats.append(st)
-        if world > 1:
+        if world > 1 and not lib_gather:
             lib_streams[slot].wait_stream(torch.cuda.current_stream(device))
         ctx.render_device(ptrs[slot], args.spp, args.bounces, seed=1, part=part, flags=flags, stats=False, slot=slot)
-        if world > 1:  # the frame's one exchange step: RGB8 tiles over RCCL, then de-interleave
+        if lib_gather:  # the frame's one exchange step, on the slot's stream: RCCL all-gather of the RGB8 tiles, de-interleave kernel
+            ctx.gather_image(ptrs[slot], all_tiles[slot].ptr, images[slot].ptr, slot=slot, tile=args.tile)
+        elif world > 1:  # the same through torch.distributed
             torch.cuda.current_stream(device).wait_stream(lib_streams[slot])
             frame[0] = tl.gather_image(tiles[slot], args.width, args.width, args.tile, rank, world, dist)
         issued[0] += 1
@@ -134,7 +154,10 @@ def main():
 
     def fence():
         ctx.synchronize()
-        if world > 1:
+        if lib_gather:
+            dist.barrier()
+            ctx.synchronize()
+        elif world > 1:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -161,7 +184,7 @@ def main():
     assert len(stats) == args.steps, (len(stats), args.steps)
     rays_step = stats[-1].rays
     if world > 1:
-        cdev = device if args.backend == "nccl" else torch.device("cpu")
+        cdev = device if (args.backend == "nccl" and not lib_gather) else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -174,7 +197,9 @@ def main():
         return
 
     if args.out:
-        if world > 1:
+        if lib_gather:
+            img = images[(args.steps - 1) % n_slots].to_host().reshape(args.width, args.width, 3)
+        elif world > 1:
             img = frame[0].cpu().numpy()
         else:
             img = rt.untile(tiles[(args.steps - 1) % n_slots].to_host(), args.width, args.width, args.tile)
@@ -277,6 +302,7 @@ def main():
            "config": {"workload": f"{args.scene}: {scene_text}, {info.n_objects} primitives, "
                                   f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
                       "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
+                      "gather": None if world == 1 else ("rtx_gather_image (library RCCL communicator)" if lib_gather else f"torch.distributed {args.backend}"),
                       "frames_in_flight": n_slots,
                       "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
                       "bvh": {"internal_nodes": info.n_internal, "leaves": info.n_leaves, "depth": info.depth,

@@ -30,7 +30,8 @@ typedef enum rtx_status {
     RTX_ERR_NO_SCENE = -3,   /* render before rtx_upload_scene */
     RTX_ERR_CAPACITY = -4,   /* scene exceeds a documented device limit */
     RTX_ERR_DEGENERATE = -5, /* BVH build cannot terminate (reference recurses forever, bvh.rs:221-230) */
-    RTX_ERR_IO = -6
+    RTX_ERR_IO = -6,
+    RTX_ERR_COMM = -7        /* an RCCL call failed (multi-GPU gather) */
 } rtx_status;
 
 /* Object / material / light vocabularies of the reference. */
@@ -191,6 +192,26 @@ int rtx_render_device_noalloc(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, 
 uint64_t rtx_partition_pixels(rtx_ctx *ctx, const rtx_partition *part_or_null);
 void *rtx_stream(rtx_ctx *ctx); /* hipStream_t of slot 0: rtx_render_device, rtx_render_device_noalloc, the trace calls */
 int rtx_synchronize(rtx_ctx *ctx); /* waits for every slot; reports a capacity overflow of an asynchronous render */
+
+/* Multi-GPU, one process per GPU: the frame is cut into tiles dealt round-robin over the ranks
+ * (rtx_partition), the scene is replicated, and ONE collective per frame brings the finished RGB8
+ * tiles together -- the receive loop of world.rs:70-74.  The context owns the RCCL communicator.
+ *   rank 0: rtx_comm_unique_id(id); hand the 128 bytes to every rank by any means (file, socket, MPI)
+ *   every rank: rtx_init(local device) ... rtx_comm_init(ctx, id, rank, nranks) (collective)
+ *   per frame:  rtx_render_device_slot(ctx, slot, .., part = {tile, rank, nranks}, .., d_tiles, NULL)
+ *               rtx_gather_image(ctx, slot, tile, d_tiles, d_all, d_image)   (collective, asynchronous)
+ * d_tiles must hold rtx_gather_bytes_per_rank() bytes (the largest rank's share: ranks with one
+ * tile fewer leave the tail untouched), d_all nranks times that, d_image (optional) W*H*3: the
+ * assembled row-major image, on every rank.  The gather runs on the slot's stream: behind the
+ * slot's render, ahead of its next one.  With one rank it is a device copy plus the reordering. */
+#define RTX_COMM_ID_BYTES 128
+int rtx_comm_unique_id(void *id_128_bytes);
+int rtx_comm_init(rtx_ctx *ctx, const void *id_128_bytes, int rank, int nranks);
+int rtx_comm_rank(rtx_ctx *ctx);
+int rtx_comm_size(rtx_ctx *ctx);
+uint64_t rtx_gather_bytes_per_rank(rtx_ctx *ctx, uint32_t tile);
+int rtx_gather_image(rtx_ctx *ctx, uint32_t slot, uint32_t tile, const void *d_tiles_rgb8, void *d_all_tiles,
+                     void *d_image_rgb8_or_null);
 
 /* Hit-ID parity: closest hit of the primary ray of sample `sample` of every pixel
  * (camera.rs:32-47 + bvh.rs:33-35).  out_obj: object index in rtx_scene_desc order,

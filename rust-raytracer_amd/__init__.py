@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 MEDIA_DIR = os.path.join(REPO_ROOT, "assets")
 
 RTX_OK = 0
-RTX_ERR_INVALID, RTX_ERR_HIP, RTX_ERR_NO_SCENE, RTX_ERR_CAPACITY, RTX_ERR_DEGENERATE, RTX_ERR_IO = -1, -2, -3, -4, -5, -6
+RTX_ERR_INVALID, RTX_ERR_HIP, RTX_ERR_NO_SCENE, RTX_ERR_CAPACITY, RTX_ERR_DEGENERATE, RTX_ERR_IO, RTX_ERR_COMM = -1, -2, -3, -4, -5, -6, -7
 FLAG_COUNT_VISITS = 1
 FLAG_REFERENCE_TRAVERSAL = 2
 
@@ -100,6 +100,13 @@ def lib():
     L.rtx_set_build_threads.argtypes = [vp, C.c_int]
     L.rtx_render_device_slot.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Partition), C.c_uint32,
                                          vp, C.POINTER(Stats)]
+    L.rtx_comm_unique_id.argtypes = [C.c_char_p]
+    L.rtx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.rtx_comm_rank.argtypes = [vp]
+    L.rtx_comm_size.argtypes = [vp]
+    L.rtx_gather_bytes_per_rank.argtypes = [vp, C.c_uint32]
+    L.rtx_gather_bytes_per_rank.restype = C.c_uint64
+    L.rtx_gather_image.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rtx_slot_count.argtypes = [vp]
     L.rtx_slot_stream.argtypes = [vp, C.c_uint32]
     L.rtx_slot_stream.restype = vp
@@ -369,6 +376,18 @@ class Context:
                                                  C.byref(st) if stats else None))
         return st
 
+    def comm_init(self, comm_id, rank, nranks):
+        """rtx_comm_init: joins the RCCL communicator that `comm_id` (comm_unique_id() of rank 0) names."""
+        self._check(lib().rtx_comm_init(self._h, comm_id, rank, nranks))
+
+    def gather_bytes_per_rank(self, tile=32):
+        return lib().rtx_gather_bytes_per_rank(self._h, tile)
+
+    def gather_image(self, d_tiles, d_all, d_image=0, slot=0, tile=32):
+        """rtx_gather_image: all-gather of the ranks' tile buffers on the slot's stream, then the row-major image."""
+        self._check(lib().rtx_gather_image(self._h, slot, tile, C.c_void_p(d_tiles), C.c_void_p(d_all),
+                                           C.c_void_p(d_image) if d_image else None))
+
     @property
     def slots(self):
         return self._check(lib().rtx_slot_count(self._h))
@@ -486,6 +505,15 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    """rtx_comm_unique_id: 128 bytes that name a new RCCL communicator (rank 0 makes them, every rank gets them)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().rtx_comm_unique_id(buf)
+    if rc != RTX_OK:
+        raise RtxError(rc, lib().rtx_last_error(None).decode())
+    return buf.raw
 
 
 def kernel_source_hash():

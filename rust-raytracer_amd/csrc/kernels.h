@@ -122,6 +122,11 @@ void launch_accumulate(const DeviceScene &sc, const Frame &fr, const BatchInfo &
 void launch_export_hits(const DeviceScene &sc, const Frame &fr, uint32_t n, uint32_t *out_obj, float *out_t,
                         const LaunchCfg &lc);
 void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc);
+// The frame's exchange step behind the collective: the all-gathered tile buffers of every rank
+// ([rank][local tile][row in tile][col in tile][rgb], rank_stride bytes apart) -> one row-major RGB8 image.
+// Replaces the receive loop of world.rs:70-74 (pixels[x] = colors).
+void launch_deinterleave(const uint8_t *all_tiles, size_t rank_stride, uint32_t nranks, uint32_t tile, uint32_t width,
+                         uint32_t height, uint8_t *image, hipStream_t stream);
 int query_persistent_blocks(int device);
 
 // rtx_render_device_noalloc: the wavefront state of a small render lives in a file-scope

@@ -1482,6 +1482,22 @@ __global__ void __launch_bounds__(BLOCK) export_colors_kernel(Frame fr, uint32_t
     out_rgb[(size_t)i * 3 + 2] = c.z;
 }
 
+// one thread = one pixel of the assembled image: tile gt = tile row * tiles_x + tile column belongs to rank
+// gt % nranks, where it is local tile gt / nranks
+__global__ void __launch_bounds__(BLOCK) deinterleave_kernel(const uint8_t *all_tiles, size_t rank_stride, uint32_t nranks,
+                                                             uint32_t tile, uint32_t width, uint32_t height, uint8_t *image) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t px = i % width, py = i / width, tiles_x = (width + tile - 1) / tile;
+    const uint32_t gt = (py / tile) * tiles_x + px / tile;
+    const uint8_t *src = all_tiles + (size_t)(gt % nranks) * rank_stride +
+                         ((size_t)(gt / nranks) * tile * tile + (size_t)(py % tile) * tile + px % tile) * 3;
+    uint8_t *dst = image + (size_t)i * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+
 inline int grid_for(uint32_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
 }  // namespace
@@ -1527,6 +1543,13 @@ void launch_export_hits(const DeviceScene &sc, const Frame &fr, uint32_t n, uint
 }
 void launch_export_colors(const Frame &fr, uint32_t n, float *out_rgb, const LaunchCfg &lc) {
     hipLaunchKernelGGL(export_colors_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, n, out_rgb);
+}
+
+void launch_deinterleave(const uint8_t *all_tiles, size_t rank_stride, uint32_t nranks, uint32_t tile, uint32_t width,
+                         uint32_t height, uint8_t *image, hipStream_t stream) {
+    const uint32_t n = width * height;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, stream, all_tiles, rank_stride, nranks, tile,
+                       width, height, image);
 }
 
 int query_persistent_blocks(int device) {

@@ -1,5 +1,6 @@
 // C ABI of include/rtx.h: context, scene upload, wavefront render driver.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -60,6 +61,9 @@ struct rtx_ctx {
     rtx_bvh_info info{};
     uint32_t max_bounce = 0;
     uint32_t per_hit = 0;             // work entries one closest hit can push: bounce children + non-ambient lights
+    // multi-GPU (rtx_comm_init): one process per GPU, this context's rank in the frame's tile partition
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
     // host-image renders (rtx_render, slot 0)
     uint8_t *tiles = nullptr;
     float *tiles_f32 = nullptr;
@@ -554,6 +558,7 @@ void rtx_destroy(rtx_ctx *c) {
     }
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->tiles_f32) (void)hipFree(c->tiles_f32);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
 }
 
@@ -818,6 +823,79 @@ int rtx_render(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64_t seed, const 
             if (out_f32) std::memcpy(out_f32 + dst, hf.data() + src, (size_t)w * 3 * sizeof(float));
         }
     }
+    return RTX_OK;
+}
+
+#define NCCL_TRY(ctx, expr)                                                                    \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            (ctx)->err = std::string(#expr) + ": " + ncclGetErrorString(r_);                   \
+            return RTX_ERR_COMM;                                                               \
+        }                                                                                      \
+    } while (0)
+
+int rtx_comm_unique_id(void *id_128_bytes) {
+    if (!id_128_bytes) return RTX_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == RTX_COMM_ID_BYTES, "rtx.h states the size of the RCCL id");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) {
+        g_init_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r);
+        return RTX_ERR_COMM;
+    }
+    std::memcpy(id_128_bytes, &id, sizeof id);
+    return RTX_OK;
+}
+
+int rtx_comm_init(rtx_ctx *c, const void *id_128_bytes, int rank, int nranks) {
+    if (!c || !id_128_bytes || nranks < 1 || rank < 0 || rank >= nranks) return RTX_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) {
+        NCCL_TRY(c, ncclCommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id_128_bytes, sizeof id);
+    NCCL_TRY(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank;
+    c->comm_size = nranks;
+    return RTX_OK;
+}
+
+int rtx_comm_rank(rtx_ctx *c) { return c ? c->comm_rank : RTX_ERR_INVALID; }
+int rtx_comm_size(rtx_ctx *c) { return c ? c->comm_size : RTX_ERR_INVALID; }
+
+uint64_t rtx_gather_bytes_per_rank(rtx_ctx *c, uint32_t tile) {
+    if (!c || !c->has_scene) return 0;
+    rtx_partition p{tile ? tile : 32u, 0, (uint32_t)c->comm_size};  // rank 0 owns the most tiles
+    Partition pt;
+    if (make_partition(c, &p, pt) != RTX_OK) return 0;
+    return pt.npix * 3;
+}
+
+int rtx_gather_image(rtx_ctx *c, uint32_t slot, uint32_t tile, const void *d_tiles, void *d_all, void *d_image) {
+    if (!c || !d_tiles || !d_all || slot >= c->pipes.size()) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    if (!c->comm) {
+        c->err = "rtx_comm_init has not been called";
+        return RTX_ERR_COMM;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t bytes = rtx_gather_bytes_per_rank(c, tile);
+    if (bytes == 0) {
+        c->err = "bad tile size";
+        return RTX_ERR_INVALID;
+    }
+    hipStream_t st = c->pipes[slot].main;  // behind the slot's render, before its next one
+    NCCL_TRY(c, ncclAllGather(d_tiles, d_all, (size_t)bytes, ncclUint8, c->comm, st));
+    if (d_image)
+        launch_deinterleave(static_cast<const uint8_t *>(d_all), (size_t)bytes, (uint32_t)c->comm_size, tile ? tile : 32u, c->ds.width,
+                            c->ds.height, static_cast<uint8_t *>(d_image), st);
+    HIP_TRY(c, hipGetLastError());
     return RTX_OK;
 }
 

@@ -1,0 +1,40 @@
+"""The multi-GPU exchange step behind the C ABI (rtx_comm_init / rtx_gather_image, include/rtx.h): RCCL all-gather
+of the ranks' RGB8 tile buffers on the render slot's stream, then the de-interleave kernel.  A one-GPU box can only
+run it with a communicator of ONE rank: that checks the linkage against librccl, the stream ordering behind an
+asynchronous render, and the reordering kernel (tile edges that do not divide the image).  The packing for N > 1
+ranks is covered on the CPU by tests/test_distributed.py (gloo, world size 2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("width,tile", [(96, 32), (100, 16)])
+def test_gather_image_one_rank(rt, width, tile):
+    s = rt.HostScene("basic_suzanne", width)
+    c = rt.Context(0)
+    try:
+        c.upload(s)
+        c.comm_init(rt.comm_unique_id(), 0, 1)
+        img, _ = c.render(spp=2, bounces=3, seed=6, part=(tile, 0, 1))
+        nbytes = c.gather_bytes_per_rank(tile)
+        assert nbytes == c.partition_pixels((tile, 0, 1)) * 3
+        d_tiles, d_all, d_img = rt.DeviceBuffer(nbytes, fill=1), rt.DeviceBuffer(nbytes, fill=2), rt.DeviceBuffer(width * width * 3, fill=3)
+        for slot in (0, 1):
+            c.render_device(d_tiles.ptr, 2, 3, seed=6, part=(tile, 0, 1), stats=False, slot=slot)   # asynchronous
+            c.gather_image(d_tiles.ptr, d_all.ptr, d_img.ptr, slot=slot, tile=tile)                 # behind it, same stream
+            c.slot_synchronize(slot)
+            got = d_img.to_host().reshape(width, width, 3)
+            assert np.array_equal(got, img), f"slot {slot}: {(got != img).sum()} bytes differ"
+            assert np.array_equal(d_all.to_host(), d_tiles.to_host())
+    finally:
+        c.close()
+
+
+def test_gather_without_communicator_fails(rt, gpu):
+    s = rt.HostScene("basic", 32)
+    gpu.upload(s)
+    b = rt.DeviceBuffer(32 * 32 * 3)
+    with pytest.raises(rt.RtxError) as e:
+        gpu.gather_image(b.ptr, b.ptr)
+    assert e.value.status == rt.RTX_ERR_COMM
