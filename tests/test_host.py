@@ -6,6 +6,7 @@ import hashlib
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -437,3 +438,85 @@ def test_default_camera_matrix(rt, orc):
     # centre pixel ray of the oracle points along the camera's forward axis
     ray = orc.Scene(s).generate_ray(32, 32)
     np.testing.assert_allclose(ray[3:], fwd, atol=1e-6)
+
+
+# ---------------------------------------------------------------- the Rust side of the boundary (integration/)
+_RUST_OF_CTYPES = {"c_uint": "u32", "c_uint32": "u32", "c_int": "i32", "c_int32": "i32", "c_ulong": "u64", "c_uint64": "u64",
+                   "c_float": "f32", "c_double": "f64", "c_ubyte": "u8", "c_uint8": "u8"}
+
+
+def _rust_structs(text):
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+) \{(.*?)\n\}", text, flags=re.S):
+        out[m.group(1)] = [(f.group(1), f.group(2).strip()) for f in re.finditer(r"pub (\w+): ([^,\n]+),", m.group(2))]
+    return out
+
+
+def _ctypes_field_type(t):
+    import ctypes as C
+    if hasattr(t, "_length_"):      # array
+        return f"[{_RUST_OF_CTYPES[t._type_.__name__]}; {t._length_}]"
+    if hasattr(t, "contents") or t.__name__.startswith("LP_"):   # pointer: the ABI's arrays are all borrowed inputs
+        return "*const " + _RUST_OF_CTYPES[t._type_.__name__]
+    return _RUST_OF_CTYPES[t.__name__]
+
+
+def test_rtx_sys_is_generated_from_the_header():
+    """integration/rtx-sys/src/lib.rs is what tools/gen_rtx_sys.py makes of include/rtx.h today."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rtx_sys
+    have = open(os.path.join(ROOT, "integration", "rtx-sys", "src", "lib.rs")).read()
+    assert have == gen_rtx_sys.generate(), "include/rtx.h changed: run tools/gen_rtx_sys.py"
+
+
+def test_rtx_sys_agrees_with_the_binding_the_gpu_tests_use(rt):
+    """Independent of the generator: the #[repr(C)] structs of lib.rs have the fields, order and types of the
+    ctypes Structures that every GPU test passes through the ABI, and lib.rs declares every function of rtx.h
+    with as many arguments as the header."""
+    text = open(os.path.join(ROOT, "integration", "rtx-sys", "src", "lib.rs")).read()
+    rs = _rust_structs(text)
+    for name, cls in (("rtx_scene_desc", rt.SceneDesc), ("rtx_stats", rt.Stats), ("rtx_bvh_info", rt.BvhInfo),
+                      ("rtx_partition", rt.Partition)):
+        want = [(f, _ctypes_field_type(t)) for f, t in cls._fields_]
+        assert rs[name] == want, f"{name}: {[a for a, b in zip(rs[name], want) if a != b][:3]}"
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rtx.h")).read(), flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(rtx_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", header, flags=re.S)}
+    rfns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rtx_\w+)\((.*?)\)(?: -> [^;]+)?;", text)}
+    assert set(protos) == set(rfns), set(protos) ^ set(rfns)
+    for name, args in protos.items():
+        n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        n_r = 0 if not rfns[name].strip() else rfns[name].count(",") + 1
+        assert n_c == n_r, name
+    # pointer mutability of the two calls the reference's render() patch makes
+    assert "pub fn rtx_upload_scene(ctx: *mut rtx_ctx, desc: *const rtx_scene_desc) -> c_int;" in text
+    assert "out_rgb8: *mut u8" in text and "out: *mut *mut rtx_ctx" in text
+
+
+def test_flatten_rs_fills_every_field_of_the_descriptor(rt):
+    text = open(os.path.join(ROOT, "integration", "flatten.rs")).read()
+    body = text[text.index("rtx_scene_desc {"):]
+    body = body[:body.index("\n        }")]
+    filled = re.findall(r"^\s+(\w+):", body, flags=re.M)
+    assert filled == [f for f, _ in rt.SceneDesc._fields_]
+    # and uses the vocabulary constants of the header, not literals
+    for const in ("RTX_OBJ_SPHERE", "RTX_OBJ_TRIANGLE", "RTX_OBJ_QUAD", "RTX_MAT_COMPOSITION", "RTX_TEX_IMAGE", "RTX_LIGHT_CONE"):
+        assert const in text
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference checkout exists in the authoring container only")
+def test_reference_patch_applies(tmp_path):
+    """integration/reference.patch (pub(crate) accessors, mod flatten, the new body of world::render) applies to the
+    reference's sources as they are."""
+    import shutil
+    import subprocess
+    work = tmp_path / "ref"
+    work.mkdir()
+    shutil.copytree("/root/reference/src", work / "src")
+    shutil.copy("/root/reference/Cargo.toml", work / "Cargo.toml")
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "integration", "reference.patch")], cwd=work,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.join(ROOT, "integration", "reference.patch")], cwd=work)
+    world = (work / "src" / "world.rs").read_text()
+    assert "rtx_upload_scene(ctx, &desc)" in world and "ThreadPool::new" not in world
+    assert "pub(crate) object_type" in (work / "src" / "object.rs").read_text()
