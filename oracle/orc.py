@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liboracle.so")
 _f32p, _u8p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
 
 
