@@ -435,6 +435,8 @@ __device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float
 struct Trav {
     RayCtx r;
     uint32_t cur;
+    uint32_t bank;          // a leaf set aside while the wave ran node steps (wave_step), or TRAV_DONE
+    __device__ __forceinline__ bool done() const { return (cur & bank) == TRAV_DONE; }
     float limit_plus;
     uint32_t prim;
     float t;                // closest: best hit so far; shadow: distance light -> shaded point
@@ -449,6 +451,7 @@ __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack
     s.occluded = false;
     s.limit_plus = INFINITY;
     s.cur = TRAV_DONE;
+    s.bank = TRAV_DONE;
     st.sp = 0;
     uint32_t root = REF ? sc.root_ref : sc.wroot_ref;
     if (root == NO_PRIM) return;
@@ -603,10 +606,12 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
 }
 
 // Advances a lane that holds a leaf by ONE primitive (Vec order, bvh.rs:378-389): the leaf
-// reference (first << 3 | count) shrinks from the front until it is used up.
+// reference (first << 3 | count) shrinks from the front until it is used up.  The banked leaf
+// goes first (it was reached first); only the leaf in `cur` is followed by a pop.
 template <bool COUNT, bool REF>
 __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow) {
-    uint32_t cur = s.cur;
+    const bool banked = s.bank != TRAV_DONE;
+    uint32_t cur = banked ? s.bank : s.cur;
     uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
     float tw;
     if (COUNT) s.prims++;
@@ -624,14 +629,16 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
             if (tw + 1e-4f < dist) {
                 s.occluded = true;
                 if (!REF) {  // (the verbatim traversal goes on: the reference asks for the closest hit, light.rs:90)
-                    s.cur = TRAV_DONE;
+                    s.cur = s.bank = TRAV_DONE;
                     return;
                 }
             }
             if (!REF) s.limit_plus = dist + (s.r.slack0 + 1.5e-5f * fabsf(dist));
         }
     }
-    s.cur = ((cur & 7u) > 1u) ? cur + 7u : st.pop(s.limit_plus);  // first + 1, count - 1
+    const bool more = (cur & 7u) > 1u;  // then: first + 1, count - 1
+    if (banked) s.bank = more ? cur + 7u : TRAV_DONE;
+    else s.cur = more ? cur + 7u : st.pop(s.limit_plus);
 }
 
 // One scheduling step of a wave: lanes are either at an internal node or at a primitive of
@@ -643,6 +650,9 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 #endif
 #ifndef RTX_NODE_WEIGHT
 #define RTX_NODE_WEIGHT 1
+#endif
+#ifndef RTX_LEAF_BANK
+#define RTX_LEAF_BANK 0
 #endif
 // Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
 // tools/util_probe.py prints it): wave steps and executing lanes per kind.
@@ -671,11 +681,17 @@ struct Util {
 template <bool COUNT, bool REF, bool OVH>
 __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow, LdsNodePtr lds_top,
                                           Util &u) {
-    bool at_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
-    bool at_node = !(s.cur & LEAF_BIT);
+    const bool cur_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
+    const bool at_leaf = cur_leaf || s.bank != TRAV_DONE;
+    // A lane at a leaf need not sit out a node step: it sets the leaf aside (one per lane) and goes
+    // on with the next entry of its stack.  The order of the visits changes nothing in the answer
+    // (closest hit: the minimum over (t, leaf-order index); shadow query: two flags), only what
+    // the limit prunes; the lane would have waited otherwise.
+    const bool bankable = RTX_LEAF_BANK && cur_leaf && s.bank == TRAV_DONE && st.sp > 0;
+    const bool at_node = !(s.cur & LEAF_BIT) || bankable;
     uint32_t nl = (uint32_t)__popcll(__ballot(at_leaf)), nn = (uint32_t)__popcll(__ballot(at_node));
 #ifdef RTX_UTIL_STATS
-    u.done_lanes += 64u - nl - nn;
+    u.done_lanes += (uint32_t)__popcll(__ballot(s.done()));
 #endif
     if (nl * (uint32_t)RTX_LEAF_WEIGHT >= nn * (uint32_t)RTX_NODE_WEIGHT) {
 #ifdef RTX_UTIL_STATS
@@ -684,11 +700,16 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #endif
         if (at_leaf) prim_step<COUNT, REF>(sc, s, st, shadow);
     } else {
+        if (bankable) {
+            s.bank = s.cur;
+            s.cur = st.pop(s.limit_plus);
+        }
+        const bool run = !(s.cur & LEAF_BIT);
 #ifdef RTX_UTIL_STATS
         u.node_steps++;
-        u.node_lanes += nn;
+        u.node_lanes += (uint32_t)__popcll(__ballot(run));
 #endif
-        if (at_node) node_step<COUNT, REF, OVH>(sc, s, st, lds_top);
+        if (run) node_step<COUNT, REF, OVH>(sc, s, st, lds_top);
     }
 }
 
@@ -908,6 +929,16 @@ __device__ __forceinline__ void object_uv(const PrimView &v, const Xform *xforms
 //
 // Work entry / lane tag: x = path node, y = bits 4..0 light, bit 5 light is directional, bit 6
 // shadow query (else closest hit), bit 7 (lane tag only) a ray is in flight, bits 11..8 bounce level.
+// the cost of one pass between rays in traversal steps, and the range of the waiting-lane threshold
+#ifndef RTX_EVENT_STEPS
+#define RTX_EVENT_STEPS 8
+#endif
+#ifndef RTX_REFILL_LO
+#define RTX_REFILL_LO 8
+#endif
+#ifndef RTX_REFILL_HI
+#define RTX_REFILL_HI 48
+#endif
 #ifndef RTX_SHADE_MIN
 #define RTX_SHADE_MIN 32
 #endif
@@ -953,7 +984,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     st.spill_stride = nthreads;
     st.sp = 0;
     Trav s;
-    s.cur = TRAV_DONE;
+    s.cur = s.bank = TRAV_DONE;
     s.nodes = s.prims = 0;
     s.t = 0.0f;
     s.prim = NO_PRIM;
@@ -972,13 +1003,15 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     Util util;
     WaveQueue wq;
     wq.init(fr.work, n0, nthreads / 64u, gtid / 64u);
+    uint32_t refill_min = (uint32_t)RTX_REFILL_MIN, steps_run = 0;  // wave-uniform
+    float end_rate = -1.0f;                                         // rays ending per step, running mean
 #ifdef RTX_UTIL_STATS
     const unsigned long long t_begin = wall_clock64();
     unsigned long long t_dry = 0;
     uint32_t dry_events = 0, dry_steps0 = 0, dry_fin = 0, dry_top = 0, dry_fin_c = 0;
 #endif
     for (;;) {
-        const bool idle = s.cur == TRAV_DONE;
+        const bool idle = s.done();
         const bool fin = idle && (tag & WK_BUSY);
         const unsigned long long idlem = __ballot(idle), finm = __ballot(fin);
         const uint32_t nidle = (uint32_t)__popcll(idlem), nfin = (uint32_t)__popcll(finm), nact = 64u - nidle;
@@ -988,17 +1021,32 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         // wave (of what is left of it once the queue of primaries is dry)
         const uint32_t serve = nidle < avail ? nidle : avail;
         const uint32_t pending = nfin > serve ? nfin : serve;
-        uint32_t thr = (uint32_t)RTX_REFILL_MIN;
+        uint32_t thr = refill_min;
         if (wq.exhausted) {
             const uint32_t live = nact + pending;
-            thr = live >= 4u * (uint32_t)RTX_REFILL_MIN ? (uint32_t)RTX_REFILL_MIN : (live >= 8u ? live / 4u : 1u);
+            thr = live >= 4u * refill_min ? refill_min : (live >= 8u ? live / 4u : 1u);
         }
         if (pending < thr && nact != 0u) {
             const uint32_t stop_at = nidle + (thr - pending) < 64u ? nidle + (thr - pending) : 64u;
             do {
                 wave_step<COUNT, REF, OVH>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
-            } while ((uint32_t)__popcll(__ballot(s.cur == TRAV_DONE)) < stop_at);
+                steps_run++;
+            } while ((uint32_t)__popcll(__ballot(s.done())) < stop_at);
             continue;
+        }
+        // The number of waiting lanes that pays for one pass through the code below depends on how
+        // long this wave's rays are.  With r rays ending per step and a pass that costs E steps,
+        // waiting for k lanes wastes about k*k/(2r) lane-steps of idling and 64 E of passing, so the
+        // useful share of the wave is (k - k*k/128) / (k + a) with a = E r: largest at
+        // k = sqrt(a*a + 128 a) - a.  Long rays (a soup of triangles) want a pass every few lanes,
+        // short ones (most primaries miss the model) only once most of the wave waits.
+        if (steps_run != 0u) {
+            const float r = (float)nfin / (float)steps_run;
+            end_rate = end_rate < 0.0f ? r : 0.75f * end_rate + 0.25f * r;
+            const float a = (float)RTX_EVENT_STEPS * end_rate;
+            const float k = sqrtf(a * a + 128.0f * a) - a;
+            refill_min = k < (float)RTX_REFILL_LO ? (uint32_t)RTX_REFILL_LO : (k > (float)RTX_REFILL_HI ? (uint32_t)RTX_REFILL_HI : (uint32_t)k);
+            steps_run = 0;
         }
 #ifdef RTX_UTIL_STATS
         util.events++;
