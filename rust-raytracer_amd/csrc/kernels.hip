@@ -659,6 +659,7 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 struct Util {
     uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
     uint32_t events = 0, shade_events = 0, shade_lanes = 0, start_lanes = 0, fin_lanes = 0;  // path kernel: lanes-between-rays events
+    unsigned long long step_ticks = 0;  // 100 MHz ticks inside the stepping loop (the rest of a wave's life is events)
     __device__ __forceinline__ void flush(uint32_t *ctr) {
 #ifdef RTX_UTIL_STATS
         if (lane_id() == 0) {
@@ -673,6 +674,7 @@ struct Util {
             atomicAdd(c + 7, (unsigned long long)shade_lanes);
             atomicAdd(c + 8, (unsigned long long)start_lanes);
             atomicAdd(c + 9, (unsigned long long)fin_lanes);
+            atomicAdd(c + 15, step_ticks);
         }
 #endif
     }
@@ -1028,10 +1030,16 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         }
         if (pending < thr && nact != 0u) {
             const uint32_t stop_at = nidle + (thr - pending) < 64u ? nidle + (thr - pending) : 64u;
+#ifdef RTX_UTIL_STATS
+            const unsigned long long t_s0 = wall_clock64();
+#endif
             do {
                 wave_step<COUNT, REF, OVH>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
                 steps_run++;
             } while ((uint32_t)__popcll(__ballot(s.done())) < stop_at);
+#ifdef RTX_UTIL_STATS
+            util.step_ticks += wall_clock64() - t_s0;
+#endif
             continue;
         }
         // The number of waiting lanes that pays for one pass through the code below depends on how

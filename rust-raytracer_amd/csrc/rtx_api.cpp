@@ -356,8 +356,9 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
                     std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry\n",
                                  dbg[1 + 6 * k] * 1e-5, dbg[2 + 6 * k], dbg[3 + 6 * k], dbg[4 + 6 * k], dbg[6 + 6 * k], dbg[5 + 6 * k]);
             }
-            std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms, mean / max time after the queue ran dry %.3f / %.3f ms\n",
+            std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms (%.3f ms of it in traversal steps), mean / max time after the queue ran dry %.3f / %.3f ms\n",
                          (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
+                         (double)u[15] * 1e-5 / (c->persistent_blocks * 4.0),
                          (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
         }
         float ms = 0;
