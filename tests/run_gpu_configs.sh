@@ -3,8 +3,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/configs.log
 run () { timeout -k 10 280 python -u bench.py --no-cpu-baseline --no-reference-visits "$@" 2>/dev/null | grep '^{' >> gpurun_out/configs.log || exit 1; }
-run --scene random_spheres --tris 1000 --width 1024 --spp 1 --steps 5 --warmup 1 && \
-run --scene basic_suzanne --width 1024 --spp 4 --steps 5 --warmup 1 && \
+run --scene random_spheres --tris 1000 --width 1024 --spp 1 --steps 10 --warmup 2 && \
+run --scene basic_suzanne --width 1024 --spp 4 --steps 10 --warmup 2 && \
 run --scene scan_glass --width 4096 --spp 64 --steps 1 --warmup 0 && \
 run --scene soup --width 2048 --spp 16 --steps 2 --warmup 1
 python - <<'PY'

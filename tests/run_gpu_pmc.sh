@@ -17,5 +17,10 @@ pass tcc2 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC
 pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum || exit 1
 pass tcp2 TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
+pass fetch FETCH_SIZE || exit 1
+pass write WRITE_SIZE || exit 1
 cd $R
-python tests/pmc_summary.py gpurun_out/pmc_$TAG | grep -v "COUNT\|<true" | grep -A40 "== path_kernel<false, true\|== path_ovh_kernel<false, true"
+# $WKEY (bench.py's workload key, "scene:tris:width:spp:bounces:world") -> entry of that workload in gpurun_out/pmc_$TAG/pmc.json
+if [ -n "$WKEY" ]; then cp profiles/pmc.json gpurun_out/pmc_$TAG/pmc.json 2>/dev/null; python tests/pmc_summary.py gpurun_out/pmc_$TAG gpurun_out/pmc_$TAG/pmc.json "$WKEY" "tests/run_gpu_pmc.sh, BENCH_ARGS='$BENCH_ARGS'" > gpurun_out/pmc_$TAG/summary.txt
+else python tests/pmc_summary.py gpurun_out/pmc_$TAG > gpurun_out/pmc_$TAG/summary.txt; fi
+grep -A48 "== path_kernel<false, false, true\|== path_ovh_kernel<false, true" gpurun_out/pmc_$TAG/summary.txt; tail -1 gpurun_out/pmc_$TAG/summary.txt
