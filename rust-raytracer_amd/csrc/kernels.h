@@ -100,6 +100,7 @@ struct LaunchCfg {
     int persistent_blocks;  // grid of the persistent path kernel
     bool count_visits;
     bool reference_traversal;
+    bool leaf_bank = false;  // the path kernel variant that sets leaves aside during node steps (kernels.hip, wave_step)
 };
 
 void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, const LaunchCfg &lc);

@@ -651,9 +651,10 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 #ifndef RTX_NODE_WEIGHT
 #define RTX_NODE_WEIGHT 1
 #endif
-#ifndef RTX_LEAF_BANK
-#define RTX_LEAF_BANK 0
-#endif
+// BANK (leaf banking, below) is a kernel variant of its own: it pays where rays are long and the
+// kernel is bound by VALU issue (a 20M-triangle soup: -9 % of the frame time), and costs 3-6 % where
+// rays are short -- as a run-time switch inside one kernel it cost the short-ray scenes the same
+// (registers and code in the stepping loop, not the extra visits).  The host picks per scene.
 // Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
 // tools/util_probe.py prints it): wave steps and executing lanes per kind.
 struct Util {
@@ -680,7 +681,7 @@ struct Util {
     }
 };
 
-template <bool COUNT, bool REF, bool OVH>
+template <bool COUNT, bool REF, bool OVH, bool BANK>
 __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow, LdsNodePtr lds_top,
                                           Util &u) {
     const bool cur_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
@@ -689,7 +690,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
     // on with the next entry of its stack.  The order of the visits changes nothing in the answer
     // (closest hit: the minimum over (t, leaf-order index); shadow query: two flags), only what
     // the limit prunes; the lane would have waited otherwise.
-    const bool bankable = RTX_LEAF_BANK && cur_leaf && s.bank == TRAV_DONE && st.sp > 0;
+    const bool bankable = BANK && cur_leaf && s.bank == TRAV_DONE && st.sp > 0;
     const bool at_node = !(s.cur & LEAF_BIT) || bankable;
     uint32_t nl = (uint32_t)__popcll(__ballot(at_leaf)), nn = (uint32_t)__popcll(__ballot(at_node));
 #ifdef RTX_UTIL_STATS
@@ -963,7 +964,7 @@ __device__ __forceinline__ bool outside_cone(const LightRec &L, F3 point) {
     return outside;
 }
 
-template <bool COUNT, bool REF, bool OVH, bool SHADE>
+template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK>
 __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
@@ -1034,7 +1035,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             const unsigned long long t_s0 = wall_clock64();
 #endif
             do {
-                wave_step<COUNT, REF, OVH>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
+                wave_step<COUNT, REF, OVH, BANK>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
                 steps_run++;
             } while ((uint32_t)__popcll(__ballot(s.done())) < stop_at);
 #ifdef RTX_UTIL_STATS
@@ -1316,15 +1317,15 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     }
 }
 
-template <bool COUNT, bool REF, bool SHADE>
+template <bool COUNT, bool REF, bool SHADE, bool BANK = false>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, REF, false, SHADE>(sc, fr, max_levels);
+    path_body<COUNT, REF, false, SHADE, BANK>(sc, fr, max_levels);
 }
 // The production traversal for scenes whose hits can lie outside their objects' boxes
 // (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
 template <bool COUNT, bool SHADE>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_ovh_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, false, true, SHADE>(sc, fr, max_levels);
+    path_body<COUNT, false, true, SHADE, false>(sc, fr, max_levels);
 }
 
 // ---------------------------------------------------------------- resolve
@@ -1578,6 +1579,9 @@ void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bo
     } else if (sc.overhang != 0.0f) {
         if (lc.count_visits) RTX_LAUNCH_PATH((path_ovh_kernel<true, true>));
         else RTX_LAUNCH_PATH((path_ovh_kernel<false, true>));
+    } else if (lc.leaf_bank) {
+        if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, false, true, true>));
+        else RTX_LAUNCH_PATH((path_kernel<false, false, true, true>));
     } else {
         if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, false, true>));
         else RTX_LAUNCH_PATH((path_kernel<false, false, true>));

@@ -69,6 +69,7 @@ struct rtx_ctx {
     float *tiles_f32 = nullptr;
     uint64_t tiles_cap = 0;
     uint64_t node_budget_bytes = 32ull << 30;
+    int leaf_bank = -1;               // RTX_LEAF_BANK: -1 = by scene size
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
     int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
@@ -313,6 +314,7 @@ int run_path(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, s
 }
 
 constexpr size_t EV_PER_BATCH = 3;  // path begin, path end, resolves end
+constexpr uint32_t RTX_LEAF_BANK_MIN_PRIMS = 8u << 20;  // scenes from this size on run the leaf-banking path kernel
 
 // Waits for the slot's last render and reports it (overflow flags, counters, event times).
 int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
@@ -437,6 +439,10 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{pp.main, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
                  (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    // Leaf banking pays where rays are long and the kernel is bound by VALU issue: measured -9 % on the
+    // 20M-triangle soup, +-0 on the 4M one (bound by fabric reads), +3..6 % on the scenes of a few
+    // million primitives and less.  RTX_LEAF_BANK=0/1 overrides the size rule.
+    lc.leaf_bank = c->leaf_bank < 0 ? c->ds.n_prims >= RTX_LEAF_BANK_MIN_PRIMS : c->leaf_bank != 0;
     uint8_t *tiles = d_tiles_out ? static_cast<uint8_t *>(d_tiles_out) : c->tiles;
     const bool async = !stats && d_tiles_out;
     if (!async) HIP_TRY(c, hipStreamSynchronize(pp.main));
@@ -533,6 +539,7 @@ int rtx_init(int device, rtx_ctx **out) {
         rtx_destroy(c);
         return RTX_ERR_HIP;
     }
+    if (const char *lb = std::getenv("RTX_LEAF_BANK")) c->leaf_bank = std::atoi(lb) != 0;
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
     if (const char *mn = std::getenv("RTX_MIN_BATCHES")) c->min_batches = (uint32_t)std::min(64, std::max(1, std::atoi(mn)));

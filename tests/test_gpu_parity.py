@@ -434,6 +434,35 @@ def test_slots_overlap_and_agree(rt, gpu, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("name,width,param,spp", [("soup", 256, 200000, 4), ("scan_glass", 256, 30000, 4), ("basic_suzanne", 192, 0, 2),
+                                                  ("random_spheres", 128, 300, 2)])
+def test_leaf_banking_variant_is_exact(rt, orc, monkeypatch, name, width, param, spp):
+    """The path kernel variant that sets leaves aside during node steps (chosen by scene size; forced here with
+    RTX_LEAF_BANK) visits the tree in another order: frames, ray counts and primary hits must not differ in a bit
+    from the default variant's, and the frame must match the oracle like the default's."""
+    s = rt.HostScene(name, width, param)
+    frames, stats = [], []
+    for bank in ("0", "1"):
+        monkeypatch.setenv("RTX_LEAF_BANK", bank)
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            buf = rt.DeviceBuffer(c.partition_pixels(None) * 3)
+            st = c.render_device(buf.ptr, spp, 4, seed=3)
+            frames.append(buf.to_host())
+            stats.append(st)
+        finally:
+            c.close()
+    assert frames[0].any()
+    assert np.array_equal(frames[0], frames[1]), f"{(frames[0] != frames[1]).sum()} bytes differ"
+    assert (stats[0].primary_rays, stats[0].bounce_rays, stats[0].shadow_rays) == (stats[1].primary_rays, stats[1].bounce_rays, stats[1].shadow_rays)
+    o = orc.Scene(s)
+    img_o, st_o = o.render(spp=spp, bounces=4, seed=3)
+    img_g = rt.untile(frames[1], width, width, 32)
+    ok, frac, worst = _image_close(img_g, img_o)
+    assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
+
+
 def test_errors(rt, gpu):
     c = rt.Context(0)
     with pytest.raises(rt.RtxError) as e:
