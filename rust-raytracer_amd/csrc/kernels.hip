@@ -661,6 +661,7 @@ struct Util {
     uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
     uint32_t events = 0, shade_events = 0, shade_lanes = 0, start_lanes = 0, fin_lanes = 0;  // path kernel: lanes-between-rays events
     unsigned long long step_ticks = 0;  // 100 MHz ticks inside the stepping loop (the rest of a wave's life is events)
+    unsigned long long sec_ticks[4] = {0, 0, 0, 0};  // ... and inside an event: finished rays, shading pass, stack / queue, ray begin
     __device__ __forceinline__ void flush(uint32_t *ctr) {
 #ifdef RTX_UTIL_STATS
         if (lane_id() == 0) {
@@ -676,6 +677,7 @@ struct Util {
             atomicAdd(c + 8, (unsigned long long)start_lanes);
             atomicAdd(c + 9, (unsigned long long)fin_lanes);
             atomicAdd(c + 15, step_ticks);
+            for (int k = 0; k < 4; k++) atomicAdd(c + 16 + k, sec_ticks[k]);
         }
 #endif
     }
@@ -1071,6 +1073,12 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             dry_fin_c += (uint32_t)__popcll(__ballot(fin && !(tag & WK_SHADOW)));
         }
 #endif
+#ifdef RTX_UTIL_STATS
+        unsigned long long t_sec = wall_clock64();
+#define RTX_SECTION(k) { const unsigned long long t_now = wall_clock64(); util.sec_ticks[k] += t_now - t_sec; t_sec = t_now; }
+#else
+#define RTX_SECTION(k)
+#endif
         // ---- the rays that have just finished
         if (nfin != 0u) {
             if (SHADE && fin && (tag & WK_SHADOW)) {
@@ -1107,6 +1115,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             }
             if (fin) tag &= ~WK_BUSY;
         }
+        RTX_SECTION(0)
         // ---- shading pass over the listed hits (world.rs:120-125, material.rs:185-203): which lights
         // want a shadow query, the bounce children; run by the idle lanes once SHADE_MIN hits wait
         if constexpr (SHADE) {
@@ -1203,6 +1212,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 if (mine) fr.link[hnode] = make_uint2(lit0 | (level << LINK_LEVEL_SHIFT) | (nb << LINK_NB_SHIFT), first);
             }
         }
+        RTX_SECTION(1)
         // ---- work for the idle lanes: the top of the wave's stack first, then new primaries
         {
             const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
@@ -1245,6 +1255,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
 #ifdef RTX_UTIL_STATS
             util.start_lanes += (uint32_t)__popcll(__ballot(got));
 #endif
+            RTX_SECTION(2)
             // ---- begin the new rays
             if (got) {
                 const float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
@@ -1274,6 +1285,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                     trav_begin<REF, OVH>(sc, s, st);  // (a ray that misses the root box is done at once)
                 }
             }
+            RTX_SECTION(3)
         }
     }
     // what is left of the wave's last run of pool nodes

@@ -362,6 +362,9 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
                          (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
                          (double)u[15] * 1e-5 / (c->persistent_blocks * 4.0),
                          (double)u[13] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[14] * 1e-5);
+            std::fprintf(stderr, "util events, mean per wave: finished rays %.3f ms, shading pass %.3f ms, stack / queue %.3f ms, ray begin %.3f ms\n",
+                         (double)u[16] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[17] * 1e-5 / (c->persistent_blocks * 4.0),
+                         (double)u[18] * 1e-5 / (c->persistent_blocks * 4.0), (double)u[19] * 1e-5 / (c->persistent_blocks * 4.0));
         }
         float ms = 0;
         const size_t e = EV_PER_BATCH * bi;
