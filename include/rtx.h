@@ -10,9 +10,16 @@
  * Conventions: every function returns RTX_OK (0) or a negative rtx_status and never
  * throws or aborts across the boundary; rtx_last_error() gives the text.  Input
  * pointers are borrowed for the duration of the call; output buffers are owned by the
- * caller.  One rtx_ctx per GPU, called from one host thread at a time (a render launches on
- * several streams of its own and joins them into rtx_stream() before it returns).  The library
- * has no CPU fallback: without a usable HIP device rtx_init fails.
+ * caller.  One rtx_ctx per GPU, called from one host thread at a time (a render runs on the
+ * stream of its render slot; slot 0's is rtx_stream()).  The library has no CPU fallback:
+ * without a usable HIP device rtx_init fails.
+ *
+ * Limits the reference does not have (checked at rtx_upload_scene / rtx_render*, reported as
+ * RTX_ERR_CAPACITY or RTX_ERR_INVALID with a message, never silently wrong): <= 16 lights;
+ * max_ray_bounces <= 8 (reference: u16); <= 4 reflective / refractive leaves per material;
+ * Composition nesting <= 4; <= 8,192 distinct transforms; <= 65,536 materials; <= 2^28 objects;
+ * BVH depth <= 198; < 2^32 path nodes per batch (larger frames are split into batches by the
+ * library itself, results unchanged).
  */
 #ifndef RTX_H
 #define RTX_H
