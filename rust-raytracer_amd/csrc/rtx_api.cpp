@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -45,6 +46,12 @@ struct Pipe {
     uint32_t last_batches = 0, last_levels = 0;
     uint64_t last_primary = 0;
     double last_t0 = 0;               // host time the render was enqueued at (synchronous renders: after the stream had drained)
+    // Second lane of a render that is cut into several batches: odd batches run on a stream and in
+    // wavefront buffers of their own, so that batch k's tail and resolve launches hide under batch
+    // k+1's path kernel; the accumulates stay in sample order through an event chain.  Created on
+    // the first such render.
+    std::unique_ptr<Pipe> lane2;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_acc[2] = {nullptr, nullptr};
 };
 
 struct rtx_ctx {
@@ -70,6 +77,7 @@ struct rtx_ctx {
     uint64_t tiles_cap = 0;
     uint64_t node_budget_bytes = 32ull << 30;
     int leaf_bank = -1;               // RTX_LEAF_BANK: -1 = by scene size
+    int batch_lanes = 2;              // RTX_BATCH_LANES=1: the batches of a render all run on the slot's own stream
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
     int build_threads = 0;            // rtx_set_build_threads (0: min(16, hardware threads))
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
@@ -301,15 +309,15 @@ struct Batch {
 // path kernel (every ray of every bounce level), then the colours bottom-up, one streaming pass
 // per level.  Records 3 timing events starting at events[ev0] when timing is on: path begin, path
 // end, resolves end.
-int run_path(rtx_ctx *c, Pipe &pp, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
-    lc.stream = pp.main;
-    if (timing) (void)hipEventRecord(pp.events[ev0], pp.main);
-    if (levels) launch_path(c->ds, pp.fr, levels, true, lc);   // trace_ray(.., 0) is the background (world.rs:116-117)
-    if (timing) (void)hipEventRecord(pp.events[ev0 + 1], pp.main);
+int run_path(rtx_ctx *c, Pipe &lane, std::vector<hipEvent_t> &events, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
+    lc.stream = lane.main;
+    if (timing) (void)hipEventRecord(events[ev0], lane.main);
+    if (levels) launch_path(c->ds, lane.fr, levels, true, lc);   // trace_ray(.., 0) is the background (world.rs:116-117)
+    if (timing) (void)hipEventRecord(events[ev0 + 1], lane.main);
     // a level deeper than 0 exists only if some material spawns bounce rays
-    for (int k = (c->max_bounce ? (int)levels - 1 : 0); k >= 1; k--) launch_resolve(c->ds, pp.fr, (uint32_t)k, lc);
-    launch_resolve(c->ds, pp.fr, 0, lc);
-    if (timing) (void)hipEventRecord(pp.events[ev0 + 2], pp.main);
+    for (int k = (c->max_bounce ? (int)levels - 1 : 0); k >= 1; k--) launch_resolve(c->ds, lane.fr, (uint32_t)k, lc);
+    launch_resolve(c->ds, lane.fr, 0, lc);
+    if (timing) (void)hipEventRecord(events[ev0 + 2], lane.main);
     return RTX_OK;
 }
 
@@ -432,6 +440,17 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     for (auto &b : batches) n0max = std::max<uint64_t>(n0max, (uint64_t)b.npix * b.ns);
     rc = ensure_frame(c, pp, std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
     if (rc != RTX_OK) return rc;
+    const bool two_lanes = batches.size() >= 2 && c->batch_lanes >= 2;
+    if (two_lanes) {
+        if (!pp.lane2) {
+            pp.lane2.reset(new Pipe());
+            HIP_TRY(c, hipStreamCreateWithFlags(&pp.lane2->main, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&pp.ev_begin, &pp.ev_end, &pp.ev_acc[0], &pp.ev_acc[1]})
+                HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        rc = ensure_frame(c, *pp.lane2, std::max<uint64_t>(n0max, 1), std::max(levels, 1u));
+        if (rc != RTX_OK) return rc;
+    }
     rc = ensure_pixels(c, pp, pt.npix, d_tiles_out == nullptr, want_f32);
     if (rc != RTX_OK) return rc;
     rc = ensure_counter_slots(c, pp, (uint32_t)batches.size());
@@ -450,8 +469,14 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     const bool async = !stats && d_tiles_out;
     if (!async) HIP_TRY(c, hipStreamSynchronize(pp.main));
     pp.last_t0 = now_s();
+    if (two_lanes) {  // the second lane begins behind everything the slot's stream holds (the previous frame, its gather)
+        HIP_TRY(c, hipEventRecord(pp.ev_begin, pp.main));
+        HIP_TRY(c, hipStreamWaitEvent(pp.lane2->main, pp.ev_begin, 0));
+    }
     for (size_t bi = 0; bi < batches.size(); bi++) {
         const Batch &b = batches[bi];
+        Pipe &lane = (two_lanes && (bi & 1)) ? *pp.lane2 : pp;
+        lc.stream = lane.main;
         BatchInfo info{};
         info.q0 = b.q0;
         info.npix = b.npix;
@@ -467,15 +492,22 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
         info.tiles_x = pt.tiles_x;
         info.tiles_y = pt.tiles_y;
         info.max_levels = levels;
-        rc = reset_counters(c, pp);
+        rc = reset_counters(c, lane);
         if (rc != RTX_OK) return rc;
-        launch_raygen(c->ds, pp.fr, info, lc);
-        rc = run_path(c, pp, lc, levels, timing, ev_per_batch * bi);
+        launch_raygen(c->ds, lane.fr, info, lc);
+        rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi);
         if (rc != RTX_OK) return rc;
-        // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream
-        launch_accumulate(c->ds, pp.fr, info, pp.sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
-        HIP_TRY(c, hipMemcpyAsync(pp.h_counters + bi * CTR_WORDS, pp.fr.counters, CTR_WORDS * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, pp.main));
+        // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream,
+        // or, with two lanes, batch k's accumulate waits for batch k-1's on the other stream
+        if (two_lanes && bi > 0) HIP_TRY(c, hipStreamWaitEvent(lane.main, pp.ev_acc[(bi - 1) & 1], 0));
+        launch_accumulate(c->ds, lane.fr, info, pp.sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
+        if (two_lanes) HIP_TRY(c, hipEventRecord(pp.ev_acc[bi & 1], lane.main));
+        HIP_TRY(c, hipMemcpyAsync(pp.h_counters + bi * CTR_WORDS, lane.fr.counters, CTR_WORDS * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, lane.main));
+    }
+    if (two_lanes) {  // the slot's stream ends behind the second lane: whoever waits for the slot waits for the frame
+        HIP_TRY(c, hipEventRecord(pp.ev_end, pp.lane2->main));
+        HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.ev_end, 0));
     }
     HIP_TRY(c, hipGetLastError());
     // valid primary samples of this rank
@@ -543,6 +575,7 @@ int rtx_init(int device, rtx_ctx **out) {
         return RTX_ERR_HIP;
     }
     if (const char *lb = std::getenv("RTX_LEAF_BANK")) c->leaf_bank = std::atoi(lb) != 0;
+    if (const char *bl = std::getenv("RTX_BATCH_LANES")) c->batch_lanes = std::atoi(bl);
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
         if (std::atoi(rv)) c->force_flags |= RTX_FLAG_REFERENCE_TRAVERSAL;
     if (const char *mn = std::getenv("RTX_MIN_BATCHES")) c->min_batches = (uint32_t)std::min(64, std::max(1, std::atoi(mn)));
@@ -561,6 +594,13 @@ void rtx_destroy(rtx_ctx *c) {
         if (pp.main) (void)hipStreamSynchronize(pp.main);
     free_all(c->scene_allocs);
     for (auto &pp : c->pipes) {
+        if (pp.lane2) {
+            if (pp.lane2->main) (void)hipStreamSynchronize(pp.lane2->main);
+            free_all(pp.lane2->allocs);
+            if (pp.lane2->main) (void)hipStreamDestroy(pp.lane2->main);
+        }
+        for (hipEvent_t e : {pp.ev_begin, pp.ev_end, pp.ev_acc[0], pp.ev_acc[1]})
+            if (e) (void)hipEventDestroy(e);
         free_all(pp.allocs);
         if (pp.sum) (void)hipFree(pp.sum);
         if (pp.h_counters) (void)hipHostFree(pp.h_counters);
@@ -796,7 +836,7 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     rc = reset_counters(c, np);
     if (rc != RTX_OK) return rc;
     launch_raygen(c->ds, np.fr, info, lc);
-    rc = run_path(c, np, lc, levels, false, 0);
+    rc = run_path(c, np, np.events, lc, levels, false, 0);
     if (rc != RTX_OK) return rc;
     launch_accumulate(c->ds, np.fr, info, sum, static_cast<uint8_t *>(d_tiles), nullptr, lc);
     HIP_TRY(c, hipGetLastError());
@@ -1007,7 +1047,7 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         (void)reset_counters(c, pp);
         launch_load_rays(pp.fr, d_rays, m, lc);
         if (out_rgb) {
-            if (run_path(c, pp, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
+            if (run_path(c, pp, pp.events, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
             launch_export_colors(pp.fr, m, d_f, lc);
             if (e == hipSuccess) e = hipMemcpyAsync(out_rgb + i0 * 3, d_f, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream);
         } else {

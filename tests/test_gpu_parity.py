@@ -386,14 +386,44 @@ def test_sample_batching_is_exact(rt, gpu, monkeypatch):
     gpu.upload(s)
     ref, _ = gpu.render(spp=5, bounces=4, seed=9)
     monkeypatch.setenv("RTX_NODE_BUDGET_MB", "1")
-    c2 = rt.Context(0)
-    try:
-        c2.upload(s)
-        img, st = c2.render(spp=5, bounces=4, seed=9)
-        assert st.batches > 1
-        assert np.array_equal(img, ref)
-    finally:
-        c2.close()
+    # the batches alternate between two lanes (streams, wavefront buffers) by default; one lane: all on the slot's stream
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("RTX_BATCH_LANES", lanes)
+        c2 = rt.Context(0)
+        try:
+            c2.upload(s)
+            img, st = c2.render(spp=5, bounces=4, seed=9)
+            assert st.batches > 1
+            assert np.array_equal(img, ref), f"lanes {lanes}"
+            # a second frame right behind the first, asynchronously, then a synchronous one in the same slot
+            buf = rt.DeviceBuffer(c2.partition_pixels(None) * 3)
+            c2.render_device(buf.ptr, 5, 4, seed=9, stats=False)
+            st2 = c2.render_device(buf.ptr, 5, 4, seed=9)
+            assert st2.batches == st.batches and st2.rays == st.rays
+            assert np.array_equal(rt.untile(buf.to_host(), 64, 64, 32), ref), f"lanes {lanes}, device tiles"
+        finally:
+            c2.close()
+
+
+def test_batched_glass_frame_two_lanes(rt, monkeypatch):
+    """A frame of many batches with bounce levels (pool nodes, resolve launches per level) is byte-identical
+    whether its batches run on one lane or alternate between two."""
+    s = rt.HostScene("scan_glass", 256, 30000)
+    frames = []
+    monkeypatch.setenv("RTX_MIN_BATCHES", "5")
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("RTX_BATCH_LANES", lanes)
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            buf = rt.DeviceBuffer(c.partition_pixels(None) * 3)
+            st = c.render_device(buf.ptr, 16, 4, seed=2)
+            assert st.batches >= 4
+            frames.append((buf.to_host(), st.rays))
+        finally:
+            c.close()
+    assert frames[0][0].any() and frames[0][1] == frames[1][1]
+    assert np.array_equal(frames[0][0], frames[1][0])
 
 
 def test_slots_overlap_and_agree(rt, gpu, monkeypatch):
