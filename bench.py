@@ -97,10 +97,23 @@ def main():
     rt = importlib.import_module("rust-raytracer_amd")
     tl = importlib.import_module("rust-raytracer_amd.tiles") if world > 1 and not lib_gather else None
     ctx = rt.Context(local_rank)
+    host_gather = False
     if lib_gather:
-        ids = [rt.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], rank, world)
+        # The library's communicator; should RCCL refuse on any rank (rendezvous, a trial gather), every rank falls
+        # back to gathering the tiles through the host over gloo, and the line says so -- the run is not lost.
+        ok, why = 1, ""
+        try:
+            ids = [rt.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init(ids[0], rank, world)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            print(f"[bench rank {rank}] RCCL communicator unavailable ({why or 'another rank failed'}): tiles gathered through the host (gloo)",
+                  file=sys.stderr, flush=True)
+            lib_gather, host_gather = False, True
     t0 = time.time()
     scene = rt.HostScene(args.scene, args.width, args.tris)
     t_scene = time.time() - t0
@@ -117,6 +130,11 @@ def main():
         ptrs = [t.ptr for t in tiles]
         all_tiles = [rt.DeviceBuffer(nbytes * world) for _ in range(n_slots)]
         images = [rt.DeviceBuffer(args.width * args.width * 3) for _ in range(n_slots)]
+    elif host_gather:
+        nbytes = ctx.gather_bytes_per_rank(args.tile)
+        tiles = [rt.DeviceBuffer(nbytes) for _ in range(n_slots)]
+        ptrs = [t.ptr for t in tiles]
+        host_all = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(world)]
     elif world > 1:
         n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
         assert npix <= n_pad * args.tile * args.tile
@@ -138,11 +156,14 @@ def main():
             st = ctx.slot_stats(slot)                 # the frame this slot rendered n_slots steps ago (waits for it only)
             if keep:
                 stats.append(st)
-        if world > 1 and not lib_gather:
+        if world > 1 and not lib_gather and not host_gather:
             lib_streams[slot].wait_stream(torch.cuda.current_stream(device))
         ctx.render_device(ptrs[slot], args.spp, args.bounces, seed=1, part=part, flags=flags, stats=False, slot=slot)
         if lib_gather:  # the frame's one exchange step, on the slot's stream: RCCL all-gather of the RGB8 tiles, de-interleave kernel
             ctx.gather_image(ptrs[slot], all_tiles[slot].ptr, images[slot].ptr, slot=slot, tile=args.tile)
+        elif host_gather:  # fallback: D2H, gloo all-gather, (the image is assembled from host_all on demand)
+            ctx.slot_synchronize(slot)
+            dist.all_gather(host_all, torch.from_numpy(tiles[slot].to_host()))
         elif world > 1:  # the same through torch.distributed
             torch.cuda.current_stream(device).wait_stream(lib_streams[slot])
             frame[0] = tl.gather_image(tiles[slot], args.width, args.width, args.tile, rank, world, dist)
@@ -157,7 +178,7 @@ def main():
 
     def fence():
         ctx.synchronize()
-        if lib_gather:
+        if lib_gather or host_gather:
             dist.barrier()
             ctx.synchronize()
         elif world > 1:
@@ -206,7 +227,7 @@ def main():
         n_slots = 1
         stats[:] = timed_stats
     if world > 1:
-        cdev = device if (args.backend == "nccl" and not lib_gather) else torch.device("cpu")
+        cdev = device if (args.backend == "nccl" and not lib_gather and not host_gather) else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -221,6 +242,9 @@ def main():
     if args.out:
         if lib_gather:
             img = images[(args.steps - 1) % n_slots].to_host().reshape(args.width, args.width, 3)
+        elif host_gather:
+            tl = importlib.import_module("rust-raytracer_amd.tiles")
+            img = tl.assemble(torch.stack(host_all).reshape(world, -1, args.tile, args.tile, 3), args.width, args.width, args.tile, world).numpy()
         elif world > 1:
             img = frame[0].cpu().numpy()
         else:
@@ -324,7 +348,9 @@ def main():
            "config": {"workload": f"{args.scene}: {scene_text}, {info.n_objects} primitives, "
                                   f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
                       "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
-                      "gather": None if world == 1 else ("rtx_gather_image (library RCCL communicator)" if lib_gather else f"torch.distributed {args.backend}"),
+                      "gather": None if world == 1 else ("rtx_gather_image (library RCCL communicator)" if lib_gather else
+                                                         "FALLBACK: tiles through the host over gloo (RCCL communicator unavailable)" if host_gather else
+                                                         f"torch.distributed {args.backend}"),
                       "frames_in_flight": n_slots,
                       "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
                       "bvh": {"internal_nodes": info.n_internal, "leaves": info.n_leaves, "depth": info.depth,
