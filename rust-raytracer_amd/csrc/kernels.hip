@@ -39,6 +39,7 @@ hipError_t noalloc_scratch_address(int device, void **ptr) {
 namespace {
 
 constexpr int BLOCK = 256;
+constexpr int RESOLVE_SCAN = 8;  // stretches of BLOCK pool nodes a resolve block lists before it works them off
 // Threads per block of the two persistent trace kernels (measured: 64 / 128 / 256 equal on
 // the headline frame, 512 / 1024 -10..15 %: wave slots come back block by block).
 #ifndef RTX_TRACE_BLOCK
@@ -1401,101 +1402,128 @@ __device__ __forceinline__ F3 texture_sample(const DeviceScene &sc, const Materi
 // Level 0 = the batch's primary samples, nodes [0, n0); the nodes of a deeper level are those
 // pool nodes [n0, n0 + pool) whose link carries that level (runs of the pool belong to waves, so
 // the levels are interleaved; unused slots of a run are marked as holes).
+// Colour of one path node (its bounce children, if any, have theirs).
+__device__ __forceinline__ void resolve_node(const DeviceScene &sc, const Frame &fr, F3 bg, uint32_t node, uint2 lk) {
+    float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+    uint32_t prim = __float_as_uint(d4.w);
+    F3 res;
+    if (prim >= INVALID_PRIM) {
+        res = prim == INVALID_PRIM ? f3(0.f, 0.f, 0.f) : bg;  // world.rs:127-130
+    } else {
+        F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
+        F3 p = o + o4.w * d;
+        PrimView pv = load_prim(sc.prims + prim);
+        MaterialRec m = sc.mats[pv.mat];
+        F3 surface = texture_sample(sc, m, pv, p);  // material.rs:229-230
+        F3 normal = f3(0.f, 0.f, 0.f);
+        bool have_normal = false;
+        // accumulator stack of the Composition fold (material.rs:129-143), depth <= 4, in
+        // registers: a dynamically indexed array would live in scratch memory
+        F3 acc0 = f3(0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        int asp = 0;
+        F3 val = f3(0.f, 0.f, 0.f);
+        for (uint32_t k = 0; k < m.prog_count; k++) {
+            MatInstr ins = sc.prog[m.prog_first + k];
+            switch (ins.op) {
+                case OP_BEGIN:
+                    if (asp == 0) acc0 = f3(0.f, 0.f, 0.f);
+                    else if (asp == 1) acc1 = f3(0.f, 0.f, 0.f);
+                    else if (asp == 2) acc2 = f3(0.f, 0.f, 0.f);
+                    else if (asp == 3) acc3 = f3(0.f, 0.f, 0.f);
+                    asp++;
+                    break;
+                case OP_ITEM: {
+                    F3 term = cscale(val, ins.p0);
+                    if (asp == 1) acc0 = cadd(acc0, term);
+                    else if (asp == 2) acc1 = cadd(acc1, term);
+                    else if (asp == 3) acc2 = cadd(acc2, term);
+                    else if (asp == 4) acc3 = cadd(acc3, term);
+                    break;
+                }
+                case OP_END:
+                    asp--;
+                    if (asp == 0) val = acc0;
+                    else if (asp == 1) val = acc1;
+                    else if (asp == 2) val = acc2;
+                    else if (asp == 3) val = acc3;
+                    break;
+                case OP_PHONG: {  // material.rs:144-184
+                    if (!have_normal) {
+                        normal = object_normal(pv, sc.xforms, p);
+                        have_normal = true;
+                    }
+                    F3 sum = f3(0.f, 0.f, 0.f);
+                    for (uint32_t l = 0; l < sc.n_lights; l++) {
+                        if (!(lk.x & (1u << l))) continue;
+                        const LightRec &L = sc.lights[l];
+                        F3 lcol = f3(L.color[0], L.color[1], L.color[2]);
+                        F3 lc;
+                        if (L.type == LIGHT_AMBIENT) lc = lcol;
+                        else if (L.type == 2u) {
+                            float pm = phong_multiple(-f3(L.dir[0], L.dir[1], L.dir[2]), normal, d, ins.p0, ins.p1, ins.p2);
+                            lc = cscale(lcol, pm);
+                        } else {
+                            F3 light_dir = f3(L.pos[0], L.pos[1], L.pos[2]) - p;
+                            float fo = falloff_at(L, p);
+                            float pm = phong_multiple(normalize(light_dir), normal, d, ins.p0, ins.p1, ins.p2);
+                            lc = cscale(cscale(lcol, fo), pm);
+                        }
+                        sum = cadd(sum, cmul(surface, lc));
+                    }
+                    val = sum;
+                    break;
+                }
+                case OP_REFLECT:
+                case OP_REFRACT: {
+                    if (lk.y != NO_PRIM) {
+                        float4 c = fr.color[lk.y + ins.arg];
+                        val = f3(c.x, c.y, c.z);
+                    } else {
+                        val = bg;  // trace_ray(.., 0) (world.rs:116-117)
+                    }
+                    break;
+                }
+                default: val = crgb(0.5f, 0.5f, 0.5f); break;  // material.rs:204
+            }
+        }
+        res = val;
+    }
+    fr.color[node] = make_float4(res.x, res.y, res.z, 1.0f);
+}
+
 __global__ void __launch_bounds__(BLOCK) resolve_kernel(DeviceScene sc, Frame fr, uint32_t level) {
     const uint32_t n0 = fr.counters[CTR_LEVEL_COUNT];
-    const uint32_t base = level == 0u ? 0u : n0;
-    const uint32_t count = level == 0u ? n0 : min(fr.counters[CTR_POOL], fr.node_cap - n0);
     const uint32_t nthreads = gridDim.x * BLOCK;
     const F3 bg = f3(sc.background[0], sc.background[1], sc.background[2]);
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += nthreads) {
-        uint32_t node = base + i;
-        const uint2 lk = fr.link[node];
-        if (level != 0u && ((lk.x >> LINK_LEVEL_SHIFT) & 15u) != level) continue;
-        float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
-        uint32_t prim = __float_as_uint(d4.w);
-        F3 res;
-        if (prim >= INVALID_PRIM) {
-            res = prim == INVALID_PRIM ? f3(0.f, 0.f, 0.f) : bg;  // world.rs:127-130
-        } else {
-            F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
-            F3 p = o + o4.w * d;
-            PrimView pv = load_prim(sc.prims + prim);
-            MaterialRec m = sc.mats[pv.mat];
-            F3 surface = texture_sample(sc, m, pv, p);  // material.rs:229-230
-            F3 normal = f3(0.f, 0.f, 0.f);
-            bool have_normal = false;
-            // accumulator stack of the Composition fold (material.rs:129-143), depth <= 4, in
-            // registers: a dynamically indexed array would live in scratch memory
-            F3 acc0 = f3(0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            int asp = 0;
-            F3 val = f3(0.f, 0.f, 0.f);
-            for (uint32_t k = 0; k < m.prog_count; k++) {
-                MatInstr ins = sc.prog[m.prog_first + k];
-                switch (ins.op) {
-                    case OP_BEGIN:
-                        if (asp == 0) acc0 = f3(0.f, 0.f, 0.f);
-                        else if (asp == 1) acc1 = f3(0.f, 0.f, 0.f);
-                        else if (asp == 2) acc2 = f3(0.f, 0.f, 0.f);
-                        else if (asp == 3) acc3 = f3(0.f, 0.f, 0.f);
-                        asp++;
-                        break;
-                    case OP_ITEM: {
-                        F3 term = cscale(val, ins.p0);
-                        if (asp == 1) acc0 = cadd(acc0, term);
-                        else if (asp == 2) acc1 = cadd(acc1, term);
-                        else if (asp == 3) acc2 = cadd(acc2, term);
-                        else if (asp == 4) acc3 = cadd(acc3, term);
-                        break;
-                    }
-                    case OP_END:
-                        asp--;
-                        if (asp == 0) val = acc0;
-                        else if (asp == 1) val = acc1;
-                        else if (asp == 2) val = acc2;
-                        else if (asp == 3) val = acc3;
-                        break;
-                    case OP_PHONG: {  // material.rs:144-184
-                        if (!have_normal) {
-                            normal = object_normal(pv, sc.xforms, p);
-                            have_normal = true;
-                        }
-                        F3 sum = f3(0.f, 0.f, 0.f);
-                        for (uint32_t l = 0; l < sc.n_lights; l++) {
-                            if (!(lk.x & (1u << l))) continue;
-                            const LightRec &L = sc.lights[l];
-                            F3 lcol = f3(L.color[0], L.color[1], L.color[2]);
-                            F3 lc;
-                            if (L.type == LIGHT_AMBIENT) lc = lcol;
-                            else if (L.type == 2u) {
-                                float pm = phong_multiple(-f3(L.dir[0], L.dir[1], L.dir[2]), normal, d, ins.p0, ins.p1, ins.p2);
-                                lc = cscale(lcol, pm);
-                            } else {
-                                F3 light_dir = f3(L.pos[0], L.pos[1], L.pos[2]) - p;
-                                float fo = falloff_at(L, p);
-                                float pm = phong_multiple(normalize(light_dir), normal, d, ins.p0, ins.p1, ins.p2);
-                                lc = cscale(cscale(lcol, fo), pm);
-                            }
-                            sum = cadd(sum, cmul(surface, lc));
-                        }
-                        val = sum;
-                        break;
-                    }
-                    case OP_REFLECT:
-                    case OP_REFRACT: {
-                        if (lk.y != NO_PRIM) {
-                            float4 c = fr.color[lk.y + ins.arg];
-                            val = f3(c.x, c.y, c.z);
-                        } else {
-                            val = bg;  // trace_ray(.., 0) (world.rs:116-117)
-                        }
-                        break;
-                    }
-                    default: val = crgb(0.5f, 0.5f, 0.5f); break;  // material.rs:204
-                }
-            }
-            res = val;
+    if (level == 0u) {
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n0; i += nthreads) resolve_node(sc, fr, bg, i, fr.link[i]);
+        return;
+    }
+    // Deeper levels: the pool interleaves the levels (about a third of the nodes of a stretch belong to
+    // this launch's), so a block first lists the matching nodes of RESOLVE_SCAN stretches of BLOCK nodes in LDS
+    // and then works the list off at full lane width.
+    __shared__ uint32_t list[RESOLVE_SCAN * BLOCK];
+    __shared__ uint32_t nlist;
+    const uint32_t count = min(fr.counters[CTR_POOL], fr.node_cap - n0);
+    for (uint32_t t0 = blockIdx.x * (RESOLVE_SCAN * BLOCK); t0 < count; t0 += gridDim.x * (RESOLVE_SCAN * BLOCK)) {
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();
+        for (uint32_t k = 0; k < (uint32_t)RESOLVE_SCAN; k++) {
+            const uint32_t i = t0 + k * BLOCK + threadIdx.x;
+            const bool match = i < count && ((fr.link[n0 + i].x >> LINK_LEVEL_SHIFT) & 15u) == level;
+            const unsigned long long m = __ballot(match);
+            uint32_t at = 0;
+            if (lane_id() == 0 && m != 0ull) at = atomicAdd(&nlist, (uint32_t)__popcll(m));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (match) list[at + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = n0 + i;
         }
-        fr.color[node] = make_float4(res.x, res.y, res.z, 1.0f);
+        __syncthreads();
+        const uint32_t n = nlist;
+        for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
+            const uint32_t node = list[j];
+            resolve_node(sc, fr, bg, node, fr.link[node]);
+        }
+        __syncthreads();
     }
 }
 
