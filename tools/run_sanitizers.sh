@@ -8,7 +8,7 @@ ROUND=${1:-r02}
 make -C rust-raytracer_amd/csrc asan -j8 > /tmp/asan_build.log 2>&1 || { tail -20 /tmp/asan_build.log; exit 1; }
 make -C oracle asan >> /tmp/asan_build.log 2>&1 || { tail -20 /tmp/asan_build.log; exit 1; }
 RTL=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
-export LD_PRELOAD=$RTL
+export LD_PRELOAD="$RTL${LD_PRELOAD:+:$LD_PRELOAD}"  # the ASan runtime first, whatever was preloaded stays
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 export RTX_LIB=$PWD/rust-raytracer_amd/librtx_hip_asan.so ORC_LIB=$PWD/oracle/liboracle_asan.so
