@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--slots", type=int, default=0, help="render slots the steps alternate between (0: one at N = 1, where the kernel times are then those of launches that have the GPU to themselves, two at N > 1)")
+    ap.add_argument("--slots", type=int, default=0, help="render slots the steps alternate between (0: one at N = 1, where the kernel times are then those of launches that have the GPU to themselves, two at N = 2..3, four from N = 4 on)")
     ap.add_argument("--also-two-slots", action="store_true", help="N = 1: after the timed region, time the same steps alternating between two slots and report them as `two_slots`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-visits", action="store_true", help="skip the untimed pass of the verbatim bvh.rs traversal")
@@ -119,7 +119,8 @@ def main():
     t_scene = time.time() - t0
     info = ctx.upload(scene)
     part = (args.tile, rank, world)
-    n_slots = max(1, min(args.slots or (1 if world == 1 else 2), ctx.slots))
+    # frames in flight: small shares of the frame want more of them (their fixed tail and launch chain hide under the others' bulk)
+    n_slots = max(1, min(args.slots or (1 if world == 1 else 2 if world < 4 else 4), ctx.slots))
     # --also-two-slots: at N = 1 the timed region uses one slot and a second, separately reported region alternates between two
     n_alloc = max(n_slots, min(2, ctx.slots)) if (world == 1 and args.also_two_slots) else n_slots
     npix = ctx.partition_pixels(part)

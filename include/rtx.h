@@ -164,7 +164,7 @@ int rtx_render(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
 int rtx_render_device(rtx_ctx *ctx, uint32_t spp, uint32_t max_bounces, uint64_t seed,
                       const rtx_partition *part_or_null, uint32_t flags,
                       void *d_tiles_rgb8, rtx_stats *stats_or_null);
-/* Render slots: a context holds rtx_slot_count() (2; RTX_PIPES) independent slots, each with its own
+/* Render slots: a context holds rtx_slot_count() (4; RTX_PIPES) independent slots, each with its own
  * stream and wavefront buffers, so that consecutive frames -- or the tile shares of a multi-GPU
  * frame sequence -- overlap on the GPU: a render ends with a drain of a few long rays that leaves
  * most of the machine idle, and the next frame's bulk fills it (the thread pool of world.rs:38-68

@@ -75,7 +75,7 @@ struct rtx_ctx {
     uint8_t *tiles = nullptr;
     float *tiles_f32 = nullptr;
     uint64_t tiles_cap = 0;
-    uint64_t node_budget_bytes = 32ull << 30;
+    uint64_t node_budget_bytes = 16ull << 30;  // wavefront state of ONE batch (a slot in use holds one, two with the second lane)
     int leaf_bank = -1;               // RTX_LEAF_BANK: -1 = by scene size
     int batch_lanes = 2;              // RTX_BATCH_LANES=1: the batches of a render all run on the slot's own stream
     uint32_t force_flags = 0;         // RTX_REFERENCE_TRAVERSAL=1: every call runs the verbatim traversal (A/B checks)
@@ -420,7 +420,7 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     // Batches: a frame whose path nodes exceed the slot's share of the node budget is cut into
     // pieces (by sample, else by pixel range) that run one after the other on the slot's stream.
     uint64_t total = pt.npix * spp;
-    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / c->pipes.size() / per_sample, 4096);
+    uint64_t cap0 = std::max<uint64_t>(c->node_budget_bytes / per_sample, 4096);
     const uint32_t want = total >= (1u << 20) ? std::max(1u, c->min_batches) : 1u;
     std::vector<Batch> batches;
     if (pt.npix <= cap0 && spp >= want) {
@@ -552,7 +552,7 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     rtx_ctx *c = new rtx_ctx();
     c->device = device;
-    int n_pipes = 2;
+    int n_pipes = 4;  // buffers of a slot are allocated by its first render
     if (const char *np = std::getenv("RTX_PIPES")) n_pipes = std::min(4, std::max(1, std::atoi(np)));
     c->pipes.resize((size_t)n_pipes);
     e = hipSuccess;

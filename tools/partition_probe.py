@@ -29,6 +29,17 @@ for n in ns:
         ctx.render_device(tiles[k & 1].ptr, 16, 4, seed=1, part=part, stats=False, slot=k & 1)
     ctx.synchronize()
     d2 = (time.perf_counter() - t0) / K * 1e3
+    more = ""
+    for S in range(3, ctx.slots + 1):  # RTX_PIPES=3/4: more frames in flight
+        bufs = [rt.DeviceBuffer(ctx.partition_pixels(part) * 3) for _ in range(S)]
+        for k in range(S):
+            ctx.render_device(bufs[k].ptr, 16, 4, seed=1, part=part, stats=False, slot=k)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            ctx.render_device(bufs[k % S].ptr, 16, 4, seed=1, part=part, stats=False, slot=k % S)
+        ctx.synchronize()
+        more += f", {S} slots {(time.perf_counter() - t0) / K * 1e3:.3f}"
     full = full or d2 * n
     print(f"1/{n} of the frame: {dt:.3f} ms/frame alone ({st.rays/dt/1e3:.0f} Mrays/s), queued in one slot {dq:.3f}, "
-          f"alternating slots {d2:.3f} ms/frame = {full / n / d2 * 100:.0f} % of 1/{n} of the whole frame's time", flush=True)
+          f"alternating slots {d2:.3f} ms/frame = {full / n / d2 * 100:.0f} % of 1/{n} of the whole frame's time{more}", flush=True)
