@@ -219,6 +219,12 @@ int rtx_comm_size(rtx_ctx *ctx);
 uint64_t rtx_gather_bytes_per_rank(rtx_ctx *ctx, uint32_t tile);
 int rtx_gather_image(rtx_ctx *ctx, uint32_t slot, uint32_t tile, const void *d_tiles_rgb8, void *d_all_tiles,
                      void *d_image_rgb8_or_null);
+/* The reordering half of rtx_gather_image on its own, for hosts that bring their own collective (MPI,
+ * a communicator of their own): d_all_tiles holds the tile buffers of `nranks` ranks, each
+ * rtx_partition_pixels(ctx, {tile, 0, nranks}) * 3 bytes apart, as an all-gather leaves them;
+ * d_image_rgb8 receives the row-major W*H*3 image.  Asynchronous, on the slot's stream. */
+int rtx_assemble_image(rtx_ctx *ctx, uint32_t slot, uint32_t tile, uint32_t nranks, const void *d_all_tiles,
+                       void *d_image_rgb8);
 
 /* Hit-ID parity: closest hit of the primary ray of sample `sample` of every pixel
  * (camera.rs:32-47 + bvh.rs:33-35).  out_obj: object index in rtx_scene_desc order,

@@ -107,6 +107,7 @@ def lib():
     L.rtx_gather_bytes_per_rank.argtypes = [vp, C.c_uint32]
     L.rtx_gather_bytes_per_rank.restype = C.c_uint64
     L.rtx_gather_image.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rtx_assemble_image.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.rtx_slot_count.argtypes = [vp]
     L.rtx_slot_stream.argtypes = [vp, C.c_uint32]
     L.rtx_slot_stream.restype = vp
@@ -387,6 +388,10 @@ class Context:
         """rtx_gather_image: all-gather of the ranks' tile buffers on the slot's stream, then the row-major image."""
         self._check(lib().rtx_gather_image(self._h, slot, tile, C.c_void_p(d_tiles), C.c_void_p(d_all),
                                            C.c_void_p(d_image) if d_image else None))
+
+    def assemble_image(self, d_all, d_image, nranks, slot=0, tile=32):
+        """rtx_assemble_image: the reordering half of gather_image alone (all-gathered tile buffers of nranks ranks -> image)."""
+        self._check(lib().rtx_assemble_image(self._h, slot, tile, nranks, C.c_void_p(d_all), C.c_void_p(d_image)))
 
     @property
     def slots(self):

@@ -950,6 +950,23 @@ int rtx_gather_image(rtx_ctx *c, uint32_t slot, uint32_t tile, const void *d_til
     return RTX_OK;
 }
 
+int rtx_assemble_image(rtx_ctx *c, uint32_t slot, uint32_t tile, uint32_t nranks, const void *d_all, void *d_image) {
+    if (!c || !d_all || !d_image || slot >= c->pipes.size()) return RTX_ERR_INVALID;
+    if (!c->has_scene) {
+        c->err = "no scene uploaded";
+        return RTX_ERR_NO_SCENE;
+    }
+    rtx_partition p0{tile ? tile : 32u, 0, nranks};
+    Partition pt;
+    int rc = make_partition(c, &p0, pt);  // rank 0 owns the largest share: the stride between the ranks' buffers
+    if (rc != RTX_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_deinterleave(static_cast<const uint8_t *>(d_all), (size_t)pt.npix * 3, nranks, pt.tile, c->ds.width, c->ds.height,
+                        static_cast<uint8_t *>(d_image), c->pipes[slot].main);
+    HIP_TRY(c, hipGetLastError());
+    return RTX_OK;
+}
+
 int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed, uint32_t flags, uint32_t *out_obj,
                       float *out_t) {
     if (!c || !out_obj || !out_t) return RTX_ERR_INVALID;

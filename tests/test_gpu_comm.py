@@ -1,8 +1,9 @@
 """The multi-GPU exchange step behind the C ABI (rtx_comm_init / rtx_gather_image, include/rtx.h): RCCL all-gather
 of the ranks' RGB8 tile buffers on the render slot's stream, then the de-interleave kernel.  A one-GPU box can only
 run it with a communicator of ONE rank: that checks the linkage against librccl, the stream ordering behind an
-asynchronous render, and the reordering kernel (tile edges that do not divide the image).  The packing for N > 1
-ranks is covered on the CPU by tests/test_distributed.py (gloo, world size 2)."""
+asynchronous render, and the reordering kernel (tile edges that do not divide the image).  The reordering for N > 1
+ranks runs here too, through rtx_assemble_image on a gathered buffer put together on one GPU (2..16 ranks); the
+packing logic is also covered on the CPU by tests/test_distributed.py (gloo, world size 2)."""
 import numpy as np
 import pytest
 
@@ -27,6 +28,33 @@ def test_gather_image_one_rank(rt, width, tile):
             got = d_img.to_host().reshape(width, width, 3)
             assert np.array_equal(got, img), f"slot {slot}: {(got != img).sum()} bytes differ"
             assert np.array_equal(d_all.to_host(), d_tiles.to_host())
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("width,tile,nranks", [(128, 32, 2), (100, 16, 3), (160, 32, 8), (96, 32, 16)])
+def test_assemble_image_of_many_ranks(rt, width, tile, nranks):
+    """What N ranks' all-gather leaves behind, produced on one GPU: every rank's share rendered into its stretch of
+    the gathered buffer; the de-interleave kernel must turn it into the image a single rank renders (ragged tile
+    counts, more ranks than tiles in a row, tile edges that do not divide the image)."""
+    s = rt.HostScene("basic_suzanne", width)
+    c = rt.Context(0)
+    try:
+        c.upload(s)
+        img, _ = c.render(spp=2, bounces=3, seed=6)
+        stride = c.partition_pixels((tile, 0, nranks)) * 3
+        d_all = rt.DeviceBuffer(stride * nranks, fill=7)
+        for r in range(nranks):
+            share = c.partition_pixels((tile, r, nranks)) * 3
+            assert share <= stride
+            if share:
+                c.render_device(d_all.ptr + r * stride, 2, 3, seed=6, part=(tile, r, nranks), stats=False, slot=r % c.slots)
+        c.synchronize()
+        d_img = rt.DeviceBuffer(width * width * 3, fill=3)
+        c.assemble_image(d_all.ptr, d_img.ptr, nranks, slot=0, tile=tile)
+        c.slot_synchronize(0)
+        got = d_img.to_host().reshape(width, width, 3)
+        assert np.array_equal(got, img), f"{(got != img).sum()} bytes differ"
     finally:
         c.close()
 
