@@ -200,8 +200,9 @@ size_t layout_frame(uint8_t *base, uint64_t n0, uint64_t node_cap, size_t thread
     fr.link = (uint2 *)take(node_cap * sizeof(uint2));
     fr.color = (float4 *)take(node_cap * sizeof(float4));
     fr.wstack = (uint2 *)take((threads / 64) * (wstack_cap + SHADE_LIST) * sizeof(uint2));
-    fr.counters = (uint32_t *)take(CTR_WORDS * sizeof(uint32_t));
-    fr.work = (uint32_t *)take(WORK_WORDS * sizeof(uint32_t));
+    // queue heads and counter block are one stretch: one memset clears both (reset_counters)
+    fr.work = (uint32_t *)take((WORK_WORDS + CTR_WORDS) * sizeof(uint32_t));
+    fr.counters = fr.work ? fr.work + WORK_WORDS : nullptr;
     fr.spill = (uint32_t *)take(threads * spill_entries * sizeof(uint32_t) * 2);
     if (sum) *sum = (float4 *)take(npix * sizeof(float4));
     fr.node_cap = (uint32_t)node_cap;
@@ -240,8 +241,9 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     HIP_TRY(c, alloc((void **)&pp.fr.link, node_cap * sizeof(uint2)));
     HIP_TRY(c, alloc((void **)&pp.fr.color, node_cap * sizeof(float4)));
     HIP_TRY(c, alloc((void **)&pp.fr.wstack, (threads / 64) * ((size_t)wcap + SHADE_LIST) * sizeof(uint2)));
-    HIP_TRY(c, alloc((void **)&pp.fr.counters, (CTR_WORDS + 256) * sizeof(uint32_t)));  // (+ straggler list of diagnostic builds)
-    HIP_TRY(c, alloc((void **)&pp.fr.work, WORK_WORDS * sizeof(uint32_t)));
+    // queue heads, counter block (+ straggler list of diagnostic builds): one stretch, cleared by one memset
+    HIP_TRY(c, alloc((void **)&pp.fr.work, (WORK_WORDS + CTR_WORDS + 256) * sizeof(uint32_t)));
+    pp.fr.counters = pp.fr.work + WORK_WORDS;
     // stack overflow beyond the LDS entries, sized from the uploaded tree (not MAX_TREE_DEPTH)
     HIP_TRY(c, alloc((void **)&pp.fr.spill, threads * c->spill_entries * sizeof(uint32_t) * 2));  // (ref, t)
     pp.spill_entries = c->spill_entries;
@@ -254,10 +256,12 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
 }
 
 int reset_counters(rtx_ctx *c, Pipe &pp) {
-    HIP_TRY(c, hipMemsetAsync(pp.fr.counters, 0, CTR_WORDS * sizeof(uint32_t), pp.main));
-    if (std::getenv("RTX_UTIL_PRINT") && pp.allocs.size()) HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_WORDS, 0, 256 * sizeof(uint32_t), pp.main));
-    HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, WORK_WORDS * sizeof(uint32_t), pp.main));
-    HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_UTIL + 20, 0xFF, 8, pp.main));  // earliest wave begin (diagnostic builds): atomicMin
+    static const bool util_print = std::getenv("RTX_UTIL_PRINT") != nullptr;  // diagnostic builds (-DRTX_UTIL_STATS)
+    HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, (WORK_WORDS + CTR_WORDS) * sizeof(uint32_t), pp.main));
+    if (util_print) {
+        if (pp.allocs.size()) HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_WORDS, 0, 256 * sizeof(uint32_t), pp.main));
+        HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_UTIL + 20, 0xFF, 8, pp.main));  // earliest wave begin: atomicMin
+    }
     return RTX_OK;
 }
 
