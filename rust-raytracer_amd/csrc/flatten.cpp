@@ -1,8 +1,15 @@
 #include "flatten.h"
 
 #include <cmath>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <thread>
 
 namespace rtx {
 
@@ -265,8 +272,16 @@ float hit_overhang(const rtx_scene_desc &d, std::vector<float> &per_object) {
     return worst == 0.0 ? 0.0f : (float)(worst * 1.0001 + 1e-7);
 }
 
-int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err) {
+int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err, int threads) {
     out = FlatScene();
+    const bool timing = std::getenv("RTX_FLATTEN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "flatten %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
     if (d.n_xforms == 0 || d.n_xforms > 8192) {
         err = "scene needs between 1 and 8192 transforms";
         return d.n_xforms == 0 ? RTX_ERR_INVALID : RTX_ERR_CAPACITY;
@@ -368,51 +383,82 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             l.cos_full = (full == full && full > 1.0 && full < 89.0) ? (float)std::cos(full * 3.14159265358979323846 / 180.0) : 2.0f;
         }
     }
+    lap("tables");
     // primitives in leaf order
     uint32_t n = d.n_objects;
     out.prims.resize((size_t)n + 3);  // 3 zero records of padding: a leaf visit touches first..first+3
     std::memset(out.prims.data() + n, 0, 3 * sizeof(Prim));
     out.prim_obj = bvh.leaf_order;
-    for (uint32_t k = 0; k < n; k++) {
-        uint32_t o = bvh.leaf_order[k];
-        const float *v = d.obj_verts + (size_t)o * 12;
-        Prim &p = out.prims[k];
-        std::memset(&p, 0, sizeof(p));
-        int type = d.obj_type[o];
-        int xf = d.obj_xform[o], mat = d.obj_material[o];
-        if (type < 0 || type > 2 || xf < 0 || (uint32_t)xf >= d.n_xforms || mat < 0 || (uint32_t)mat >= d.n_materials) {
+    // (one gather of the objects' rows into leaf order: independent per primitive, spread over the host threads)
+    std::atomic<bool> bad{false};
+    auto fill = [&](uint32_t k0, uint32_t k1, uint32_t &max_bounce) {
+        for (uint32_t k = k0; k < k1; k++) {
+            uint32_t o = bvh.leaf_order[k];
+            const float *v = d.obj_verts + (size_t)o * 12;
+            Prim &p = out.prims[k];
+            std::memset(&p, 0, sizeof(p));
+            int type = d.obj_type[o];
+            int xf = d.obj_xform[o], mat = d.obj_material[o];
+            if (type < 0 || type > 2 || xf < 0 || (uint32_t)xf >= d.n_xforms || mat < 0 || (uint32_t)mat >= d.n_materials) {
+                bad = true;
+                return;
+            }
+            if (type == RTX_OBJ_SPHERE) {
+                p.v[0] = v[0];
+                p.v[1] = v[1];
+                p.v[2] = v[2];
+                p.v[3] = v[3];
+                p.v[4] = v[3] * v[3];  // radius.powf(2.0) (object.rs:154)
+            } else {
+                int nv = type == RTX_OBJ_QUAD ? 12 : 9;
+                for (int j = 0; j < nv; j++) p.v[j] = v[j];
+                V3 a = v3(v[0], v[1], v[2]), b = v3(v[3], v[4], v[5]);
+                V3 e = type == RTX_OBJ_QUAD ? v3(v[9], v[10], v[11]) : v3(v[6], v[7], v[8]);
+                V3 nn = normalize(cross(b - a, e - a));  // object.rs:168,191
+                p.n[0] = nn.x;
+                p.n[1] = nn.y;
+                p.n[2] = nn.z;
+            }
+            p.meta = (uint32_t)type | ((uint32_t)xf << 2) | (xf_identity[xf] ? 0x8000u : 0u) | ((uint32_t)mat << 16);
+            if (mat_bounce[mat] > max_bounce) max_bounce = mat_bounce[mat];
+        }
+    };
+    {
+        const uint32_t nt = n < (1u << 16) ? 1u : (uint32_t)std::max(1, std::min(threads, 64));
+        std::vector<uint32_t> mb(nt, 0u);
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nt; t++)
+            pool.emplace_back(fill, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt), std::ref(mb[t]));
+        fill(0, (uint32_t)((uint64_t)n / nt), mb[0]);
+        for (auto &th : pool) th.join();
+        for (uint32_t t = 0; t < nt; t++) out.max_bounce = std::max(out.max_bounce, mb[t]);
+        if (bad) {
             err = "object with bad type / transform / material index";
             return RTX_ERR_INVALID;
         }
-        if (type == RTX_OBJ_SPHERE) {
-            p.v[0] = v[0];
-            p.v[1] = v[1];
-            p.v[2] = v[2];
-            p.v[3] = v[3];
-            p.v[4] = v[3] * v[3];  // radius.powf(2.0) (object.rs:154)
-        } else {
-            int nv = type == RTX_OBJ_QUAD ? 12 : 9;
-            for (int j = 0; j < nv; j++) p.v[j] = v[j];
-            V3 a = v3(v[0], v[1], v[2]), b = v3(v[3], v[4], v[5]);
-            V3 e = type == RTX_OBJ_QUAD ? v3(v[9], v[10], v[11]) : v3(v[6], v[7], v[8]);
-            V3 nn = normalize(cross(b - a, e - a));  // object.rs:168,191
-            p.n[0] = nn.x;
-            p.n[1] = nn.y;
-            p.n[2] = nn.z;
-        }
-        p.meta = (uint32_t)type | ((uint32_t)xf << 2) | (xf_identity[xf] ? 0x8000u : 0u) | ((uint32_t)mat << 16);
-        if (mat_bounce[mat] > out.max_bounce) out.max_bounce = mat_bounce[mat];
     }
+    lap("primitives");
     std::vector<float> obj_ovh;
     out.overhang = hit_overhang(d, obj_ovh);
+    lap("overhang");
     // tree
     if (!bvh.nodes.empty()) {
+        // the binary view (reference traversal, digest) and the wide view write disjoint parts of `out`:
+        // the binary one runs on a thread of its own beside the wide one
         Emit e{bvh, out};
         out.nodes.reserve(bvh.nodes.size() / 2 + 1);
-        float total = 0.0f;
-        out.root_ref = e.emit(0, total);
-        out.total_sa = total;
+        out.preorder_sizes.reserve(bvh.nodes.size());
+        std::thread binary([&] {
+            float total = 0.0f;
+            out.root_ref = e.emit(0, total);
+            out.total_sa = total;
+        });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{binary};
         if (bvh.nodes[0].left < 0) {
+            binary.join();
             out.wide_root_ref = out.root_ref;
         } else {
             // children are numbered after their parent (bvh_build.cpp), so one descending pass
@@ -432,6 +478,8 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             out.wnodes.reserve(bvh.nodes.size() / 4 + 1);
             w.run(0);
             out.wide_root_ref = 0;
+            binary.join();
+            lap("tree views");
         }
         for (int k = 0; k < 3; k++) {
             out.root_mn[k] = bvh.nodes[0].mn[k];

@@ -35,6 +35,6 @@ struct FlatScene {
 // every object's own value.  Expects validated object indices.
 float hit_overhang(const rtx_scene_desc &d, std::vector<float> &per_object);
 
-int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err);
+int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, std::string &err, int threads = 1);
 
 }  // namespace rtx

@@ -639,7 +639,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if (rc != RTX_OK) return rc;
     double t1 = now_s();
     FlatScene fs;
-    rc = flatten_scene(*d, bvh, fs, c->err);
+    rc = flatten_scene(*d, bvh, fs, c->err, threads);
     if (rc != RTX_OK) return rc;
     // stack need: one entry per level (reference traversal), up to three per wide level
     if (bvh.depth + 2 > (uint32_t)MAX_TREE_DEPTH || 3 * fs.wide_depth + 2 > (uint32_t)MAX_TREE_DEPTH) {
@@ -1108,7 +1108,7 @@ int rtx_host_bvh_digest(const rtx_scene_desc *d, int threads, uint32_t *leaf_ord
         return rc;
     }
     FlatScene fs;
-    rc = flatten_scene(*d, bvh, fs, err);
+    rc = flatten_scene(*d, bvh, fs, err, threads > 0 ? threads : 1);
     if (rc != RTX_OK) {
         g_init_error = err;
         return rc;
