@@ -306,6 +306,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
                 "launches_per_step": launches_per_step, "slots": n_slots, "resolve_ms_per_step": round(r_ms, 4),
                 "rays_per_step": int(t_rays), "bytes_per_ray": round(t_bytes / max(t_rays, 1), 1), "valu": valu,
+                "max_records_one_ray": int(counted.max_ray_records),
                 "per_class": {"closest": per_class(c_bytes, c_rays, counted.closest_nodes, counted.closest_prims),
                               "shadow": per_class(s_bytes, s_rays, counted.shadow_nodes, counted.shadow_prims)}}
     if ref_counted is not None:  # the reference's own traversal (both children, no pruning) on the same rays, 64-byte binary nodes

@@ -187,8 +187,10 @@ int rtx_slot_stats(rtx_ctx *ctx, uint32_t slot, rtx_stats *out);
  * rtx_render_device, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no event:
  * the wavefront state of the render (path nodes, shadow queues, counters, queue heads, stack spill,
  * pixel sums) lives in a static 64 MiB device array that each GPU holds from library load to process
- * end.  The render runs as ONE batch on a reduced grid, serially on rtx_stream(), asynchronously
- * (rtx_synchronize to wait); no stats.  A render whose state does not fit -- roughly
+ * end.  The render runs as ONE batch on a reduced grid, serially on rtx_stream(), asynchronously;
+ * no stats.  rtx_synchronize / rtx_slot_synchronize(0) wait for it and return RTX_ERR_CAPACITY if its
+ * wavefront pool or a wave's work stack overflowed (the image is then incomplete; the flag travels
+ * through a pinned word that rtx_init allocated).  A render whose state does not fit -- roughly
  * pixel slots x spp x 72 B x (bounce levels actually reachable) plus 5-20 MiB of stack spill --
  * is rejected with RTX_ERR_CAPACITY and rtx_last_error says how much it needed.  All contexts of
  * one GPU share the array: calls that overlap on one GPU (two contexts, or a second call before

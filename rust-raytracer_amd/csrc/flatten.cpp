@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <functional>
 #include <thread>
 
@@ -115,9 +116,16 @@ struct EmitWide {
             }
             WideNode w;
             std::memset(&w, 0, sizeof(w));
-            for (int k = 0; k < 4; k++) w.ref[k] = WIDE_EMPTY;
+            // an empty slot holds a NaN box: the kernels' slab test can never report it hit (node_step)
+            const float qnan = std::numeric_limits<float>::quiet_NaN();
+            for (int k = 0; k < 4; k++) {
+                w.ref[k] = WIDE_EMPTY;
+                w.mnx[k] = w.mny[k] = w.mnz[k] = w.mxx[k] = w.mxy[k] = w.mxz[k] = qnan;
+            }
             for (int k = 0; k < ns; k++) {
                 const BuildNode &c = bvh.nodes[slots[k]];
+                for (int a = 0; a < 3; a++)
+                    if (!std::isfinite(c.mn[a]) || !std::isfinite(c.mx[a])) out.nonfinite_boxes = true;
                 w.mnx[k] = c.mn[0];
                 w.mny[k] = c.mn[1];
                 w.mnz[k] = c.mn[2];
@@ -375,7 +383,7 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         l.angle_deg = d.light_angle_deg[i];
         {   // the kernels compare atan2(...) > angle_deg * (pi/180) in f32; cos of that same f32 value
             const float cut = l.angle_deg * (float)(3.14159265358979323846 / 180.0);
-            if (!(cut == cut)) l.cos_cut = 0.0f;          // NaN: every comparison is false -> the exact path decides
+            if (!(cut == cut)) l.cos_cut = -2.0f;         // NaN: `angle > NaN` is false for every point (light.rs:115): never outside
             else if (cut < 0.0f) l.cos_cut = 2.0f;        // angle >= 0 > cut: always outside
             else if (cut >= 3.14159265f) l.cos_cut = -2.0f;  // angle <= pi <= cut: never outside
             else l.cos_cut = (float)std::cos((double)cut);

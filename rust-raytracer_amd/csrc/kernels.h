@@ -50,8 +50,8 @@ enum {
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
     CTR_MAX_STEPS,          // most records visited by a single ray (COUNT)
-    CTR_UTIL = 20,          // [10] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
-    CTR_WORDS = 60
+    CTR_UTIL = 20,          // [22] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
+    CTR_WORDS = 64
 };
 // Queue heads of the persistent path kernel live in their own buffer (Frame::work): the batch's
 // primary samples are ONE queue split into QPARTS sub-queues whose head counters sit on separate
@@ -64,7 +64,7 @@ enum {
     POOL_RUN = 128,     // bounce-child path nodes a wave reserves with one atomic
     SHADE_LIST = 192    // hits a wave can have waiting for its shading pass (behind its work stack)
 };
-static_assert(CTR_BOUNCE_LO % 2 == 0 && CTR_MAX_STEPS < CTR_UTIL && CTR_UTIL + 40 <= CTR_WORDS, "64-bit counters must be 8-byte aligned");
+static_assert(CTR_BOUNCE_LO % 2 == 0 && CTR_MAX_STEPS < CTR_UTIL && CTR_UTIL + 44 <= CTR_WORDS, "64-bit counters must be 8-byte aligned");
 
 // link.x of a path node: bits 15..0 mask of the lights that reach the hit point, 19..16 bounce
 // level, 22..20 number of bounce children; link.y first bounce child (NO_PRIM: none).

@@ -157,14 +157,16 @@ struct RayCtx {
     F3 inv;         // 1/d, correctly rounded
     F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
     uint32_t xf;
-    bool exact_only;  // a zero / non-finite component: always take the division path
+    bool exact_only;  // a zero / non-finite component, or slab products that could overflow: always take the division path
+    float slack0;     // absolute pruning slack
     // axis i is ill-conditioned for pruning when |1/d_i| > ILL_INV (see init_ray): derived from
     // inv where needed, not kept in a register
-    __device__ __forceinline__ bool ill_x() const { return !(fabsf(inv.x) <= ILL_INV); }
-    __device__ __forceinline__ bool ill_y() const { return !(fabsf(inv.y) <= ILL_INV); }
-    __device__ __forceinline__ bool ill_z() const { return !(fabsf(inv.z) <= ILL_INV); }
-    __device__ __forceinline__ bool ill_any() const { return ill_x() || ill_y() || ill_z(); }
-    float slack0;     // absolute pruning slack
+    __device__ __forceinline__ float cap_x() const { return fabsf(inv.x) <= ILL_INV ? INFINITY : -INFINITY; }
+    __device__ __forceinline__ float cap_y() const { return fabsf(inv.y) <= ILL_INV ? INFINITY : -INFINITY; }
+    __device__ __forceinline__ float cap_z() const { return fabsf(inv.z) <= ILL_INV ? INFINITY : -INFINITY; }
+    __device__ __forceinline__ bool ill_any() const {
+        return !(fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)) <= ILL_INV);
+    }
 };
 
 // `identity`: both matrices of the transform are exactly the identity; M*(p,1) and M*(v,0)
@@ -185,9 +187,12 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     r.o = o;
     r.d = d;
     r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    bool fin = isfinite(r.inv.x) && isfinite(r.inv.y) && isfinite(r.inv.z) && isfinite(o.x) && isfinite(o.y) &&
-               isfinite(o.z);
-    r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
+    const bool fin = isfinite(r.inv.x) && isfinite(r.inv.y) && isfinite(r.inv.z) && isfinite(o.x) && isfinite(o.y) &&
+                     isfinite(o.z);
+    const float big = sc.coord_scale + fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const float mi = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
+    // (every slab parameter (plane - o) * inv of a ray that is not exact_only is finite: |plane|, |o| <= big)
+    r.exact_only = !fin || d.x == 0.0f || d.y == 0.0f || d.z == 0.0f || !(big * mi < 1e37f);
     // Pruning compares a box's entry / exit t with hit t values.  A hit point and the faces
     // of its leaf box agree only to eps ~ 1e-6 * scale in space (both come from f32 matrix
     // products), which is eps * |1/d_i| in t along axis i: for a ray nearly parallel to a
@@ -196,10 +201,12 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     // |1/d_i| > ILL_INV are therefore left out of the entry t that pruning looks at (a
     // normalised direction always keeps one axis with |1/d_i| <= 1.74; the centre row and
     // column of every image are such rays), and such rays do not prune boxes behind the
-    // origin; slack0 covers eps * ILL_INV for the others.
-
-    float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    r.slack0 = RTX_SLACK * (sc.coord_scale + m);
+    // origin; slack0 covers eps * ILL_INV for the others.  (Measured instead, round 3: a slack
+    // that grows with the worst axis -- the 5 % of rays with such an axis then prune so little
+    // that single rays visit 1,500 records and make the launch's tail; and slab parameters in
+    // fma form, fma(plane, 1/d, -(o/d)) -- their absolute error u |o_i / d_i| widens the band
+    // of those same rays until they visit every box near their path.)
+    r.slack0 = RTX_SLACK * big;
     // Pruning also equates the slab parameter t with the distance that a hit reports, which
     // holds for |d| = 1.  Ray::new's normalisation loses that for directions whose squared
     // length leaves the normal f32 range (|d| ~ 1e-23: the dot product is a denormal with a
@@ -410,23 +417,28 @@ __device__ __forceinline__ void cswap(float &ta, uint32_t &ra, float &tb, uint32
     rb = rhi;
 }
 
-// Reciprocal slab test of one box (not for exact_only rays): entry/exit t, `miss` when the
-// intervals are clearly separated, `sure` when they clearly overlap; anything else is
-// within the f32 error of the reference's division form and must be decided by box_exact.
-// tprune: the entry t over the well-conditioned axes only (<= tmin), what pruning may use.
+// Reciprocal slab test of one box (not for exact_only rays): the entry t that pruning may use, the
+// exit t, and the two numbers that decide the box.  (plane - o) * (1/d) is within 3 u of the
+// reference's (plane - o) / d (u = 2^-24: the rounded reciprocal, the product, the division), the two
+// parameters that decide a box therefore within 6 u max(|tmin|, |tmax|) together; delta = 8 u of it.
+// diff = tmin - tmax (tmin = entry t over all three axes): the box is clearly missed when
+// diff > delta, clearly hit when diff < -delta; anything else is within the error of the
+// reference's division form and a LEAF box is then decided by box_exact.  Empty slots hold NaN
+// boxes: diff is NaN and every comparison with it false.
+// tprune: the entry t over the well-conditioned axes only (<= tmin): cx, cy, cz are +inf for
+// those and -inf for the others (RayCtx::cap_*).
 __device__ __forceinline__ void slab_fast(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                          const RayCtx &r, float &tmin, float &tmax, bool &miss, bool &sure,
-                                          float &tprune) {
+                                          const RayCtx &r, float cx, float cy, float cz, float &tprune, float &tmax,
+                                          float &diff, float &delta) {
     float ax = (mnx - r.o.x) * r.inv.x, bx = (mxx - r.o.x) * r.inv.x;
     float ay = (mny - r.o.y) * r.inv.y, by = (mxy - r.o.y) * r.inv.y;
     float az = (mnz - r.o.z) * r.inv.z, bz = (mxz - r.o.z) * r.inv.z;
     float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
-    tmin = fmaxf(fmaxf(nx, ny), nz);
-    tprune = fmaxf(fmaxf(r.ill_x() ? -INFINITY : nx, r.ill_y() ? -INFINITY : ny), r.ill_z() ? -INFINITY : nz);
+    float tmin = fmaxf(fmaxf(nx, ny), nz);
+    tprune = fmaxf(fmaxf(fminf(nx, cx), fminf(ny, cy)), fminf(nz, cz));
     tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    float delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
-    miss = tmin > tmax + delta;
-    sure = tmin <= tmax - delta;
+    diff = tmin - tmax;
+    delta = fmaxf(fabsf(tmin), fabsf(tmax)) * 4.8e-7f;
 }
 
 // Traversal state of one lane.  trav_begin() starts a ray, trav_step() advances it by one
@@ -470,9 +482,40 @@ __device__ __forceinline__ void trav_begin(const DeviceScene &sc, Trav &s, Stack
         s.cur = root;
 }
 
+// Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
+// tools/util_probe.py prints it): wave steps and executing lanes per kind.
+struct Util {
+    uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
+    uint32_t events = 0, shade_events = 0, shade_lanes = 0, start_lanes = 0, fin_lanes = 0;  // path kernel: lanes-between-rays events
+    uint32_t exact_steps = 0, exact_lanes = 0;  // node steps that ran the division path, and the lanes that needed it
+    unsigned long long step_ticks = 0;  // 100 MHz ticks inside the stepping loop (the rest of a wave's life is events)
+    unsigned long long sec_ticks[4] = {0, 0, 0, 0};  // ... and inside an event: finished rays, shading pass, stack / queue, ray begin
+    __device__ __forceinline__ void flush(uint32_t *ctr) {
+#ifdef RTX_UTIL_STATS
+        if (lane_id() == 0) {
+            unsigned long long *c = reinterpret_cast<unsigned long long *>(ctr + CTR_UTIL);
+            atomicAdd(c + 0, (unsigned long long)node_steps);
+            atomicAdd(c + 1, (unsigned long long)prim_steps);
+            atomicAdd(c + 2, (unsigned long long)node_lanes);
+            atomicAdd(c + 3, (unsigned long long)prim_lanes);
+            atomicAdd(c + 4, (unsigned long long)done_lanes);
+            atomicAdd(c + 5, (unsigned long long)events);
+            atomicAdd(c + 6, (unsigned long long)shade_events);
+            atomicAdd(c + 7, (unsigned long long)shade_lanes);
+            atomicAdd(c + 8, (unsigned long long)start_lanes);
+            atomicAdd(c + 9, (unsigned long long)fin_lanes);
+            atomicAdd(c + 15, step_ticks);
+            for (int k = 0; k < 4; k++) atomicAdd(c + 16 + k, sec_ticks[k]);
+            atomicAdd(c + 20, (unsigned long long)exact_steps);
+            atomicAdd(c + 21, (unsigned long long)exact_lanes);
+        }
+#endif
+    }
+};
+
 // Advances a lane that holds an internal node by one node.
 template <bool COUNT, bool REF, bool OVH>
-__device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st, LdsNodePtr lds_top) {
+__device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack &st, LdsNodePtr lds_top, Util &u) {
     uint32_t cur = s.cur;
     if (COUNT) s.nodes++;
     if constexpr (!REF) {
@@ -500,54 +543,64 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         }
         uint32_t r0 = __float_as_uint(rf4.x), r1 = __float_as_uint(rf4.y), r2 = __float_as_uint(rf4.z),
                  r3 = __float_as_uint(rf4.w);
-        // per slot: entry t that pruning may use (well-conditioned axes only) / exit t
+        // per slot: entry t / exit t, and whether the box is hit (inside the error band: yes, for now)
         float t0, t1, t2, t3, x0, x1, x2, x3;
-        bool m0, m1, m2, m3, s0, s1, s2, s3;
+        bool k0, k1, k2, k3, marginal;
         {
-            float e0, e1, e2, e3;  // full entry t: only decides miss / sure inside slab_fast
-            slab_fast(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, s.r, e0, x0, m0, s0, t0);
-            slab_fast(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, s.r, e1, x1, m1, s1, t1);
-            slab_fast(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, s.r, e2, x2, m2, s2, t2);
-            slab_fast(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, s.r, e3, x3, m3, s3, t3);
+            float f0, f1, f2, f3, d0, d1, d2, d3;
+            const float cx = s.r.cap_x(), cy = s.r.cap_y(), cz = s.r.cap_z();
+            slab_fast(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, s.r, cx, cy, cz, t0, x0, f0, d0);
+            slab_fast(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, s.r, cx, cy, cz, t1, x1, f1, d1);
+            slab_fast(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, s.r, cx, cy, cz, t2, x2, f2, d2);
+            slab_fast(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, s.r, cx, cy, cz, t3, x3, f3, d3);
+            k0 = f0 <= d0;
+            k1 = f1 <= d1;
+            k2 = f2 <= d2;
+            k3 = f3 <= d3;
+            marginal = fabsf(f0) <= d0 || fabsf(f1) <= d1 || fabsf(f2) <= d2 || fabsf(f3) <= d3;
         }
         // leaf slots inside the error band (and every slot of an exact_only ray) re-run the
         // reference's divisions; rare, so it sits behind ONE wave-uniform branch and reloads
         // the slot's box instead of keeping it live
         const bool eo = s.r.exact_only;
-        // branch-free: (int32)ref < -1  <=>  leaf slot that is not WIDE_EMPTY
-        bool k0 = (r0 != WIDE_EMPTY) & !m0, k1 = (r1 != WIDE_EMPTY) & !m1;  // box passed (so far)
-        bool k2 = (r2 != WIDE_EMPTY) & !m2, k3 = (r3 != WIDE_EMPTY) & !m3;
-        const bool marginal = (((int32_t)r0 < -1) & !m0 & !s0) | (((int32_t)r1 < -1) & !m1 & !s1) |
-                              (((int32_t)r2 < -1) & !m2 & !s2) | (((int32_t)r3 < -1) & !m3 & !s3);
         if (__ballot(eo | marginal) != 0ull) {
+#ifdef RTX_UTIL_STATS
+            u.exact_steps++;
+            u.exact_lanes += (uint32_t)__popcll(__ballot(eo | marginal));
+#endif
 #pragma unroll 1
             for (uint32_t k = 0; k < 4u; k++) {
                 const float *nb = reinterpret_cast<const float *>(sc.wnodes + cur) + k;
                 const uint32_t rk = reinterpret_cast<const uint32_t *>(sc.wnodes + cur)[24 + k];
                 const float bx0 = nb[0], by0 = nb[4], bz0 = nb[8], bx1 = nb[12], by1 = nb[16], bz1 = nb[20];
-                float tk, xk, pk;
-                bool mk, sk;
-                slab_fast(bx0, by0, bz0, bx1, by1, bz1, s.r, tk, xk, mk, sk, pk);
-                if ((eo & (rk != WIDE_EMPTY)) | (((int32_t)rk < -1) & !mk & !sk)) {
+                float tk, xk, fk, dk;
+                slab_fast(bx0, by0, bz0, bx1, by1, bz1, s.r, INFINITY, INFINITY, INFINITY, tk, xk, fk, dk);
+                if ((eo & (rk != WIDE_EMPTY)) | (((int32_t)rk < -1) & (fabsf(fk) <= dk))) {
                     float a, b;
-                    bool h = box_exact(bx0, by0, bz0, bx1, by1, bz1, s.r.o, s.r.d, a, b);
+                    const bool h = box_exact(bx0, by0, bz0, bx1, by1, bz1, s.r.o, s.r.d, a, b);
+                    a = fminf(a, 3.0e38f);  // (a box that is hit keeps a finite key in the sort below)
                     if (s.r.ill_any()) a = -INFINITY;  // the exact entry t is as ill-conditioned as the fast one
                     if (k == 0u) { k0 = h; t0 = a; x0 = b; }
                     if (k == 1u) { k1 = h; t1 = a; x1 = b; }
                     if (k == 2u) { k2 = h; t2 = a; x2 = b; }
                     if (k == 3u) { k3 = h; t3 = a; x3 = b; }
+                } else if (eo) {  // an empty slot: the NaN box of an exact_only ray decides nothing
+                    if (k == 0u) k0 = false;
+                    if (k == 1u) k1 = false;
+                    if (k == 2u) k2 = false;
+                    if (k == 3u) k3 = false;
                 }
             }
         }
         // A hit can lie up to ovh[k] outside its object's box in space (non-planar quads, sheared
         // spheres: flatten.cpp, hit_overhang; folded up the tree per slot), which is
-        // ovh * |1/d_i| in t on the axis that decides the box's entry or exit (the
-        // ill-conditioned axes are not looked at).  OVH: only the kernels launched for scenes
-        // with an overhang carry this code; the node's line is in the L1 by now.
+        // ovh * |1/d_i| in t on the axis that decides the box's entry or exit.  OVH: only the
+        // kernels launched for scenes with an overhang carry this code; the node's line is in
+        // the L1 by now.
         if constexpr (OVH) {
             const float4 ov = reinterpret_cast<const float4 *>(sc.wnodes + cur)[7];
-            const float g = fmaxf(fmaxf(s.r.ill_x() ? 0.0f : fabsf(s.r.inv.x), s.r.ill_y() ? 0.0f : fabsf(s.r.inv.y)),
-                                  s.r.ill_z() ? 0.0f : fabsf(s.r.inv.z));
+            const float gx = fabsf(s.r.inv.x), gy = fabsf(s.r.inv.y), gz = fabsf(s.r.inv.z);
+            const float g = fmaxf(fmaxf(gx <= ILL_INV ? gx : 0.0f, gy <= ILL_INV ? gy : 0.0f), gz <= ILL_INV ? gz : 0.0f);
             t0 -= ov.x * g;
             x0 += ov.x * g;
             t1 -= ov.y * g;
@@ -559,14 +612,14 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
         }
         // pruning: box behind the origin or beyond the best hit
         const float back = s.r.ill_any() ? -INFINITY : -s.r.slack0, lim = s.limit_plus;
-        bool h0 = k0 && !(x0 < back) && !(t0 > lim);
-        bool h1 = k1 && !(x1 < back) && !(t1 > lim);
-        bool h2 = k2 && !(x2 < back) && !(t2 > lim);
-        bool h3 = k3 && !(x3 < back) && !(t3 > lim);
-        t0 = h0 ? fminf(t0, 3.0e38f) : INFINITY;
-        t1 = h1 ? fminf(t1, 3.0e38f) : INFINITY;
-        t2 = h2 ? fminf(t2, 3.0e38f) : INFINITY;
-        t3 = h3 ? fminf(t3, 3.0e38f) : INFINITY;
+        const bool h0 = k0 && !(x0 < back) && !(t0 > lim);
+        const bool h1 = k1 && !(x1 < back) && !(t1 > lim);
+        const bool h2 = k2 && !(x2 < back) && !(t2 > lim);
+        const bool h3 = k3 && !(x3 < back) && !(t3 > lim);
+        t0 = h0 ? t0 : INFINITY;
+        t1 = h1 ? t1 : INFINITY;
+        t2 = h2 ? t2 : INFINITY;
+        t3 = h3 ? t3 : INFINITY;
         r0 = h0 ? r0 : WIDE_EMPTY;
         r1 = h1 ? r1 : WIDE_EMPTY;
         r2 = h2 ? r2 : WIDE_EMPTY;
@@ -656,34 +709,6 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 // kernel is bound by VALU issue (a 20M-triangle soup: -9 % of the frame time), and costs 3-6 % where
 // rays are short -- as a run-time switch inside one kernel it cost the short-ray scenes the same
 // (registers and code in the stepping loop, not the extra visits).  The host picks per scene.
-// Lane-utilisation census of the scheduling steps (diagnostic build -DRTX_UTIL_STATS only;
-// tools/util_probe.py prints it): wave steps and executing lanes per kind.
-struct Util {
-    uint32_t node_steps = 0, prim_steps = 0, node_lanes = 0, prim_lanes = 0, done_lanes = 0;
-    uint32_t events = 0, shade_events = 0, shade_lanes = 0, start_lanes = 0, fin_lanes = 0;  // path kernel: lanes-between-rays events
-    unsigned long long step_ticks = 0;  // 100 MHz ticks inside the stepping loop (the rest of a wave's life is events)
-    unsigned long long sec_ticks[4] = {0, 0, 0, 0};  // ... and inside an event: finished rays, shading pass, stack / queue, ray begin
-    __device__ __forceinline__ void flush(uint32_t *ctr) {
-#ifdef RTX_UTIL_STATS
-        if (lane_id() == 0) {
-            unsigned long long *c = reinterpret_cast<unsigned long long *>(ctr + CTR_UTIL);
-            atomicAdd(c + 0, (unsigned long long)node_steps);
-            atomicAdd(c + 1, (unsigned long long)prim_steps);
-            atomicAdd(c + 2, (unsigned long long)node_lanes);
-            atomicAdd(c + 3, (unsigned long long)prim_lanes);
-            atomicAdd(c + 4, (unsigned long long)done_lanes);
-            atomicAdd(c + 5, (unsigned long long)events);
-            atomicAdd(c + 6, (unsigned long long)shade_events);
-            atomicAdd(c + 7, (unsigned long long)shade_lanes);
-            atomicAdd(c + 8, (unsigned long long)start_lanes);
-            atomicAdd(c + 9, (unsigned long long)fin_lanes);
-            atomicAdd(c + 15, step_ticks);
-            for (int k = 0; k < 4; k++) atomicAdd(c + 16 + k, sec_ticks[k]);
-        }
-#endif
-    }
-};
-
 template <bool COUNT, bool REF, bool OVH, bool BANK>
 __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow, LdsNodePtr lds_top,
                                           Util &u) {
@@ -715,7 +740,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
         u.node_steps++;
         u.node_lanes += (uint32_t)__popcll(__ballot(run));
 #endif
-        if (run) node_step<COUNT, REF, OVH>(sc, s, st, lds_top);
+        if (run) node_step<COUNT, REF, OVH>(sc, s, st, lds_top, u);
     }
 }
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,9 @@ struct rtx_ctx {
     uint32_t spill_entries = 1;       // traversal-stack entries beyond LDS_STACK that the uploaded tree can need
     uint8_t *scratch = nullptr;       // this device's copy of the static scratch array (rtx_render_device_noalloc)
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
+    uint32_t *h_noalloc_flag = nullptr;  // pinned word: CTR_OVERFLOW of the last rtx_render_device_noalloc (allocated by rtx_init)
+    bool noalloc_pending = false;     // ... which nobody has looked at yet (rtx_synchronize / rtx_slot_synchronize(0) do)
+    long test_pool_nodes = -1;        // RTX_TEST_POOL_NODES: tests shrink the pool of bounce children to force the overflow report
 };
 
 namespace {
@@ -175,6 +179,7 @@ uint64_t geo_sum(uint32_t K, uint32_t levels) {
 // runs of POOL_RUN (the slack: every wave can strand one run).
 uint64_t node_capacity(const rtx_ctx *c, uint64_t n0, uint32_t levels, size_t threads) {
     const uint64_t children = n0 * (geo_sum(c->max_bounce, levels) - 1);
+    if (children && c->test_pool_nodes >= 0) return n0 + (uint64_t)c->test_pool_nodes;
     return n0 + (children ? children + (uint64_t)(threads / 64) * POOL_RUN : 0);
 }
 
@@ -338,6 +343,10 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
     for (uint32_t bi = 0; bi < pp.pending_batches && bi < pp.h_counter_slots; bi++)
         if (pp.h_counters[(size_t)bi * CTR_WORDS + CTR_OVERFLOW]) overflow = true;
     pp.pending_batches = 0;
+    if (&pp == &c->pipes[0] && c->noalloc_pending) {  // rtx_render_device_noalloc runs on slot 0's stream
+        c->noalloc_pending = false;
+        if (*c->h_noalloc_flag) overflow = true;
+    }
     if (overflow) {
         c->err = "wavefront pool overflow (internal sizing error)";
         return RTX_ERR_CAPACITY;
@@ -364,6 +373,7 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
                          (unsigned long long)u[3], (unsigned long long)u[4], (unsigned long long)u[5],
                          (unsigned long long)u[6], (unsigned long long)u[7], (unsigned long long)u[8],
                          (unsigned long long)u[9]);
+            std::fprintf(stderr, "util node steps that ran the division path: %llu (%llu lanes needed it)\n", (unsigned long long)u[20], (unsigned long long)u[21]);
             uint32_t dbg[256];
             if (pp.allocs.size() && hipMemcpy(dbg, pp.fr.counters + CTR_WORDS, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 std::fprintf(stderr, "util stragglers (> 0.6 ms after the queue ran dry): %u\n", dbg[0]);
@@ -390,6 +400,17 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
         }
     }
     return RTX_OK;
+}
+
+// Waits for every render slot (a slot's stream ends behind its second lane) and reports the first error.
+int drain_slots(rtx_ctx *c) {
+    int result = RTX_OK;
+    for (auto &pp : c->pipes) {
+        if (pp.lane2 && pp.lane2->main) (void)hipStreamSynchronize(pp.lane2->main);
+        int rc = slot_stats(c, pp, nullptr);
+        if (rc != RTX_OK && result == RTX_OK) result = rc;
+    }
+    return result;
 }
 
 int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint64_t seed, const rtx_partition *part,
@@ -478,47 +499,59 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
         HIP_TRY(c, hipEventRecord(pp.ev_begin, pp.main));
         HIP_TRY(c, hipStreamWaitEvent(pp.lane2->main, pp.ev_begin, 0));
     }
-    for (size_t bi = 0; bi < batches.size(); bi++) {
-        const Batch &b = batches[bi];
-        Pipe &lane = (two_lanes && (bi & 1)) ? *pp.lane2 : pp;
-        lc.stream = lane.main;
-        BatchInfo info{};
-        info.q0 = b.q0;
-        info.npix = b.npix;
-        info.s0 = b.s0;
-        info.ns = b.ns;
-        info.spp = spp;
-        info.use_jitter = spp != 1;  // world.rs:47-51
-        info.seed_lo = (uint32_t)seed;
-        info.seed_hi = (uint32_t)(seed >> 32);
-        info.tile = pt.tile;
-        info.rank = pt.rank;
-        info.nranks = pt.nranks;
-        info.tiles_x = pt.tiles_x;
-        info.tiles_y = pt.tiles_y;
-        info.max_levels = levels;
-        rc = reset_counters(c, lane);
-        if (rc != RTX_OK) return rc;
-        // A wave ends with the subtrees of its last 64 primaries at ever fewer active lanes: a small batch on
-        // the full grid is mostly that phase.  Small batches get a smaller grid (>= 1024 primaries per block;
-        // measured on 1/16 of the headline frame: 1.49 -> 1.40 ms alone, 0.69 -> 0.61 ms with four slots in rotation).
-        lc.persistent_blocks = c->blocks_fixed ? c->persistent_blocks
-                                               : (int)std::min<uint64_t>((uint64_t)c->persistent_blocks,
-                                                                         std::max<uint64_t>(256, (uint64_t)b.npix * b.ns / 1024));
-        launch_raygen(c->ds, lane.fr, info, lc);
-        rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi);
-        if (rc != RTX_OK) return rc;
-        // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream,
-        // or, with two lanes, batch k's accumulate waits for batch k-1's on the other stream
-        if (two_lanes && bi > 0) HIP_TRY(c, hipStreamWaitEvent(lane.main, pp.ev_acc[(bi - 1) & 1], 0));
-        launch_accumulate(c->ds, lane.fr, info, pp.sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
-        if (two_lanes) HIP_TRY(c, hipEventRecord(pp.ev_acc[bi & 1], lane.main));
-        HIP_TRY(c, hipMemcpyAsync(pp.h_counters + bi * CTR_WORDS, lane.fr.counters, CTR_WORDS * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, lane.main));
-    }
-    if (two_lanes) {  // the slot's stream ends behind the second lane: whoever waits for the slot waits for the frame
-        HIP_TRY(c, hipEventRecord(pp.ev_end, pp.lane2->main));
-        HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.ev_end, 0));
+    // (a lambda so that every error return inside joins the second lane below)
+    auto issue = [&]() -> int {
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const Batch &b = batches[bi];
+            Pipe &lane = (two_lanes && (bi & 1)) ? *pp.lane2 : pp;
+            lc.stream = lane.main;
+            BatchInfo info{};
+            info.q0 = b.q0;
+            info.npix = b.npix;
+            info.s0 = b.s0;
+            info.ns = b.ns;
+            info.spp = spp;
+            info.use_jitter = spp != 1;  // world.rs:47-51
+            info.seed_lo = (uint32_t)seed;
+            info.seed_hi = (uint32_t)(seed >> 32);
+            info.tile = pt.tile;
+            info.rank = pt.rank;
+            info.nranks = pt.nranks;
+            info.tiles_x = pt.tiles_x;
+            info.tiles_y = pt.tiles_y;
+            info.max_levels = levels;
+            rc = reset_counters(c, lane);
+            if (rc != RTX_OK) return rc;
+            // A wave ends with the subtrees of its last 64 primaries at ever fewer active lanes: a small batch on
+            // the full grid is mostly that phase.  Small batches get a smaller grid (>= 1024 primaries per block;
+            // measured on 1/16 of the headline frame: 1.49 -> 1.40 ms alone, 0.69 -> 0.61 ms with four slots in rotation).
+            lc.persistent_blocks = c->blocks_fixed ? c->persistent_blocks
+                                                   : (int)std::min<uint64_t>((uint64_t)c->persistent_blocks,
+                                                                             std::max<uint64_t>(256, (uint64_t)b.npix * b.ns / 1024));
+            launch_raygen(c->ds, lane.fr, info, lc);
+            rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi);
+            if (rc != RTX_OK) return rc;
+            // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream,
+            // or, with two lanes, batch k's accumulate waits for batch k-1's on the other stream
+            if (two_lanes && bi > 0) HIP_TRY(c, hipStreamWaitEvent(lane.main, pp.ev_acc[(bi - 1) & 1], 0));
+            launch_accumulate(c->ds, lane.fr, info, pp.sum, tiles, want_f32 ? c->tiles_f32 : nullptr, lc);
+            if (two_lanes) HIP_TRY(c, hipEventRecord(pp.ev_acc[bi & 1], lane.main));
+            HIP_TRY(c, hipMemcpyAsync(pp.h_counters + bi * CTR_WORDS, lane.fr.counters, CTR_WORDS * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, lane.main));
+        }
+        if (two_lanes) {  // the slot's stream ends behind the second lane: whoever waits for the slot waits for the frame
+            HIP_TRY(c, hipEventRecord(pp.ev_end, pp.lane2->main));
+            HIP_TRY(c, hipStreamWaitEvent(pp.main, pp.ev_end, 0));
+        }
+        return RTX_OK;
+    };
+    rc = issue();
+    if (rc != RTX_OK) {
+        // the second lane may still use the slot's sums and pinned counters: nothing of the slot is
+        // freed or reused before it has drained
+        if (two_lanes) (void)hipStreamSynchronize(pp.lane2->main);
+        (void)hipStreamSynchronize(pp.main);
+        return rc;
     }
     HIP_TRY(c, hipGetLastError());
     // valid primary samples of this rank
@@ -588,6 +621,14 @@ int rtx_init(int device, rtx_ctx **out) {
         rtx_destroy(c);
         return RTX_ERR_HIP;
     }
+    e = hipHostMalloc((void **)&c->h_noalloc_flag, sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_init_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        rtx_destroy(c);
+        return RTX_ERR_HIP;
+    }
+    *c->h_noalloc_flag = 0;
+    if (const char *tp = std::getenv("RTX_TEST_POOL_NODES")) c->test_pool_nodes = std::max(0L, std::atol(tp));
     if (const char *lb = std::getenv("RTX_LEAF_BANK")) c->leaf_bank = std::atoi(lb) != 0;
     if (const char *bl = std::getenv("RTX_BATCH_LANES")) c->batch_lanes = std::atoi(bl);
     if (const char *rv = std::getenv("RTX_REFERENCE_TRAVERSAL"))
@@ -623,6 +664,7 @@ void rtx_destroy(rtx_ctx *c) {
     }
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->tiles_f32) (void)hipFree(c->tiles_f32);
+    if (c->h_noalloc_flag) (void)hipHostFree(c->h_noalloc_flag);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
 }
@@ -636,7 +678,10 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
         return RTX_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // every slot (and its second lane, which the slot's stream ends behind) may still be reading the old
+    // scene; a render's unread overflow flag is reported here rather than carried over to the new scene
+    int pending_rc = drain_slots(c);
+    if (pending_rc != RTX_OK) return pending_rc;
     free_all(c->scene_allocs);
     c->has_scene = false;
     c->info = rtx_bvh_info{};
@@ -687,7 +732,8 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
         float bgc = d->background[k];
         ds.background[k] = bgc < 0.0f ? 0.0f : (bgc > 1.0f ? 1.0f : bgc);
     }
-    ds.coord_scale = scale;
+    // (non-finite boxes: an infinite scale makes every ray exact_only and turns pruning off, init_ray)
+    ds.coord_scale = fs.nonfinite_boxes ? INFINITY : scale;
     ds.overhang = fs.overhang;
     std::memcpy(ds.c2w, d->camera_to_world, sizeof(ds.c2w));
     ds.width = d->width;
@@ -853,6 +899,10 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     rc = run_path(c, np, np.events, lc, levels, false, 0);
     if (rc != RTX_OK) return rc;
     launch_accumulate(c->ds, np.fr, info, sum, static_cast<uint8_t *>(d_tiles), nullptr, lc);
+    // the overflow flag goes to the pinned word of rtx_init (no allocation here); rtx_synchronize /
+    // rtx_slot_synchronize(0) report it as RTX_ERR_CAPACITY
+    HIP_TRY(c, hipMemcpyAsync(c->h_noalloc_flag, np.fr.counters + CTR_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    c->noalloc_pending = true;
     HIP_TRY(c, hipGetLastError());
     return RTX_OK;
 }
@@ -917,6 +967,8 @@ int rtx_comm_init(rtx_ctx *c, const void *id_128_bytes, int rank, int nranks) {
     if (!c || !id_128_bytes || nranks < 1 || rank < 0 || rank >= nranks) return RTX_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->comm) {
+        int rc = drain_slots(c);  // a gather of the old communicator may still be in flight on a slot's stream
+        if (rc != RTX_OK) return rc;
         NCCL_TRY(c, ncclCommDestroy(c->comm));
         c->comm = nullptr;
     }

@@ -49,3 +49,25 @@ def test_noalloc_rejects_what_does_not_fit(rt, gpu):
         gpu.render_device_noalloc(out.ptr, 16, 4, seed=1)
     assert e.value.status == rt.RTX_ERR_CAPACITY
     assert "static scratch" in str(e.value)
+
+
+def test_noalloc_reports_a_pool_overflow(rt, monkeypatch):
+    """The call itself cannot read the overflow flag back (it is asynchronous and allocates nothing):
+    the flag travels through the pinned word of rtx_init and rtx_synchronize reports it.  Forced here by
+    a context whose pool of bounce children is shrunk to one run (RTX_TEST_POOL_NODES, read by rtx_init)."""
+    monkeypatch.setenv("RTX_TEST_POOL_NODES", "128")
+    ctx = rt.Context(0)
+    try:
+        ctx.upload(rt.HostScene("scan_glass", 64, 8000))   # every mesh hit spawns a mirror and a glass ray
+        out = rt.DeviceBuffer(ctx.partition_pixels((32, 0, 1)) * 3)
+        ctx.render_device_noalloc(out.ptr, 2, 4, seed=3)    # returns RTX_OK: nothing is known yet
+        with pytest.raises(rt.RtxError) as e:
+            ctx.synchronize()
+        assert e.value.status == rt.RTX_ERR_CAPACITY
+        # the flag is consumed: the next synchronize is clean, and a render that fits reports nothing
+        ctx.synchronize()
+        ctx.render_device_noalloc(out.ptr, 1, 1, seed=3)    # one level: no bounce children at all
+        ctx.synchronize()
+        out.free()
+    finally:
+        ctx.close()
