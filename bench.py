@@ -5,9 +5,13 @@ One "step" = one full pass of the trace path (raygen -> the persistent path kern
 shadow queries of every bounce level -> resolve -> RGB8 tiles) over the frame, scene already
 resident in HBM.  Consecutive steps alternate between the context's two render slots, so one frame's
 drain (a few long dependent rays) runs under the next frame's bulk; every step is a complete frame.
-With N > 1 ranks (one process per GPU, torch.distributed) the frame is split into interleaved
+With N > 1 ranks (one process per GPU, started by torch.distributed.run) the frame is split into interleaved
 32x32 tiles, every rank traces its tiles against its own copy of the scene, and the finished RGB8
-tiles are all-gathered over RCCL; total work is fixed, so scaling is "strong".
+tiles are all-gathered over RCCL by the library's own communicator; total work is fixed, so scaling is
+"strong".  The ranks meet over a plain TCP socket (rust-raytracer_amd/rendezvous.py): this process never
+imports torch, so the library runs on the RCCL and HIP runtime it is linked against and tested with
+(the line names them: config.gather).  If the communicator cannot be set up the run FAILS (exit 2);
+--allow-host-gather lets it go on with the tiles gathered through the host, and the line says so.
 
     python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -65,10 +69,13 @@ def main():
     ap.add_argument("--out", default=None, help="rank 0 writes the last frame to this PNG")
     ap.add_argument("--cpu-row-stride", type=int, default=1, help="oracle traces every n-th image row (1: the whole frame, ~10 s of CPU work)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
-                    help="N > 1: rccl = the library's own communicator (rtx_comm_init / rtx_gather_image; torch.distributed over gloo only "
-                         "hands out the RCCL id and synchronises the clocks), torch = torch.distributed all_gather_into_tensor")
+                    help="N > 1: rccl = the library's own communicator (rtx_comm_init / rtx_gather_image; the ranks meet over a TCP "
+                         "socket, torch is not imported), torch = torch.distributed all_gather_into_tensor (round-1 path, for comparison)")
     ap.add_argument("--backend", default="nccl", help="--gather torch: torch.distributed backend (gloo: rehearsal, tiles gathered via host)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1: run the N-rank code path (communicator of one rank, rtx_gather_image) all the same")
+    ap.add_argument("--allow-host-gather", action="store_true",
+                    help="N > 1: if the RCCL communicator cannot be set up, gather the tiles through the host instead of failing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,43 +83,49 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.one_device:
         local_rank = 0
-    torch = dist = device = None
-    lib_gather = world > 1 and args.gather == "rccl"
+    torch = dist = device = rdzv = None
+    multi = world > 1 or args.force_comm
+    lib_gather = multi and args.gather == "rccl"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if multi and lib_gather:
+        # host-side rendezvous only (RCCL id, barriers, two reductions): no torch in this process
+        rdzv = importlib.import_module("rust-raytracer_amd.rendezvous").Rendezvous(rank, world)
+    elif multi:
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if lib_gather:
-            dist.init_process_group("gloo")   # host-side rendezvous only: the GPU never sees torch
+        # torch first: its bundled HIP runtime has to initialise before the library's (/opt/rocm) does
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
         else:
-            # torch first: its bundled HIP runtime has to initialise before the library's (/opt/rocm) does
-            device = torch.device("cuda", local_rank)
-            torch.cuda.set_device(device)
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=device)
-            else:
-                dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend)
 
     rt = importlib.import_module("rust-raytracer_amd")
-    tl = importlib.import_module("rust-raytracer_amd.tiles") if world > 1 and not lib_gather else None
+    tl = importlib.import_module("rust-raytracer_amd.tiles") if multi and not lib_gather else None
     ctx = rt.Context(local_rank)
     host_gather = False
+    comm_text = None
     if lib_gather:
-        # The library's communicator; should RCCL refuse on any rank (rendezvous, a trial gather), every rank falls
-        # back to gathering the tiles through the host over gloo, and the line says so -- the run is not lost.
+        # The library's communicator.  Should RCCL refuse on any rank (rendezvous, a trial gather) the run fails: a curve
+        # measured through the host must not pass for an RCCL curve.  --allow-host-gather: every rank gathers through the host.
         ok, why = 1, ""
         try:
-            ids = [rt.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(ids[0], rank, world)
+            cid = rdzv.broadcast(rt.comm_unique_id().hex() if rank == 0 else None)
+            ctx.comm_init(bytes.fromhex(cid), rank, world)
+            comm_text = rt.comm_info()
         except Exception as e:  # noqa: BLE001
             ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            print(f"[bench rank {rank}] RCCL communicator unavailable ({why or 'another rank failed'}): tiles gathered through the host (gloo)",
-                  file=sys.stderr, flush=True)
+        oks = rdzv.allgather([ok, why])
+        if not all(o[0] for o in oks):
+            why = "; ".join(f"rank {r}: {o[1]}" for r, o in enumerate(oks) if not o[0])
+            if not args.allow_host_gather:
+                print(f"[bench rank {rank}] RCCL communicator unavailable ({why}); --allow-host-gather would gather the tiles through the host",
+                      file=sys.stderr, flush=True)
+                rdzv.close()
+                sys.exit(2)
+            print(f"[bench rank {rank}] RCCL communicator unavailable ({why}): tiles gathered through the host", file=sys.stderr, flush=True)
             lib_gather, host_gather = False, True
     t0 = time.time()
     scene = rt.HostScene(args.scene, args.width, args.tris)
@@ -122,7 +135,7 @@ def main():
     # frames in flight: small shares of the frame want more of them (their fixed tail and launch chain hide under the others' bulk)
     n_slots = max(1, min(args.slots or (1 if world == 1 else 2 if world < 4 else 4), ctx.slots))
     # --also-two-slots: at N = 1 the timed region uses one slot and a second, separately reported region alternates between two
-    n_alloc = max(n_slots, min(2, ctx.slots)) if (world == 1 and args.also_two_slots) else n_slots
+    n_alloc = max(n_slots, min(2, ctx.slots)) if (world == 1 and args.also_two_slots and not multi) else n_slots
     npix = ctx.partition_pixels(part)
     frame = [None]
     if lib_gather:
@@ -135,8 +148,8 @@ def main():
         nbytes = ctx.gather_bytes_per_rank(args.tile)
         tiles = [rt.DeviceBuffer(nbytes) for _ in range(n_slots)]
         ptrs = [t.ptr for t in tiles]
-        host_all = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(world)]
-    elif world > 1:
+        host_all = [None] * world
+    elif multi:
         n_pad = tl.padded_tiles_per_rank(args.width, args.width, args.tile, world)
         assert npix <= n_pad * args.tile * args.tile
         tiles = [torch.zeros(n_pad * args.tile * args.tile * 3, dtype=torch.uint8, device=device) for _ in range(n_slots)]
@@ -157,15 +170,15 @@ def main():
             st = ctx.slot_stats(slot)                 # the frame this slot rendered n_slots steps ago (waits for it only)
             if keep:
                 stats.append(st)
-        if world > 1 and not lib_gather and not host_gather:
+        if multi and not lib_gather and not host_gather:
             lib_streams[slot].wait_stream(torch.cuda.current_stream(device))
         ctx.render_device(ptrs[slot], args.spp, args.bounces, seed=1, part=part, flags=flags, stats=False, slot=slot)
         if lib_gather:  # the frame's one exchange step, on the slot's stream: RCCL all-gather of the RGB8 tiles, de-interleave kernel
             ctx.gather_image(ptrs[slot], all_tiles[slot].ptr, images[slot].ptr, slot=slot, tile=args.tile)
-        elif host_gather:  # fallback: D2H, gloo all-gather, (the image is assembled from host_all on demand)
+        elif host_gather:  # --allow-host-gather: D2H, all-gather over the rendezvous sockets (the image is assembled from host_all on demand)
             ctx.slot_synchronize(slot)
-            dist.all_gather(host_all, torch.from_numpy(tiles[slot].to_host()))
-        elif world > 1:  # the same through torch.distributed
+            host_all[:] = rdzv.allgather_bytes(tiles[slot].to_host().tobytes())
+        elif multi:  # the same through torch.distributed
             torch.cuda.current_stream(device).wait_stream(lib_streams[slot])
             frame[0] = tl.gather_image(tiles[slot], args.width, args.width, args.tile, rank, world, dist)
         issued[0] += 1
@@ -180,9 +193,9 @@ def main():
     def fence():
         ctx.synchronize()
         if lib_gather or host_gather:
-            dist.barrier()
+            rdzv.barrier()
             ctx.synchronize()
-        elif world > 1:
+        elif multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -227,16 +240,42 @@ def main():
         overlapped = {"slots": n_alloc, "ms_per_step": round(e2 / args.steps * 1e3, 3), "value": round(rays_step * args.steps / e2 / 1e6, 2), "unit": "Mrays/s"}
         n_slots = 1
         stats[:] = timed_stats
-    if world > 1:
-        cdev = device if (args.backend == "nccl" and not lib_gather and not host_gather) else torch.device("cpu")
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    one_frame = None
+    if multi and n_slots > 1:
+        # the same K steps with ONE frame in flight (the time of a frame, not the throughput of a pipeline of frames):
+        # reported beside `value` so that the scaling curve can be read either way
+        timed_stats = list(stats)
+        pipelined_slots, n_slots = n_slots, 1
+        step(keep=False)
+        drain(keep=False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(keep=False)
+        drain(keep=False)
+        fence()
+        one_frame = time.perf_counter() - t0
+        n_slots = pipelined_slots
+        stats[:] = timed_stats
+    if lib_gather or host_gather:
+        both = rdzv.allgather([elapsed, rays_step, one_frame])
+        elapsed = max(b[0] for b in both)
+        rays_step = sum(b[1] for b in both)
+        if one_frame is not None:
+            one_frame = max(b[2] for b in both)
+    elif multi:
+        cdev = device if args.backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed, one_frame or 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        one_frame = float(tt[1].item()) if one_frame is not None else None
         rr = torch.tensor([rays_step], dtype=torch.int64, device=cdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_step = int(rr.item())
     if rank != 0:
-        if world > 1:
+        if rdzv:
+            rdzv.close()
+        if dist:
             dist.destroy_process_group()
         return
 
@@ -244,9 +283,19 @@ def main():
         if lib_gather:
             img = images[(args.steps - 1) % n_slots].to_host().reshape(args.width, args.width, 3)
         elif host_gather:
-            tl = importlib.import_module("rust-raytracer_amd.tiles")
-            img = tl.assemble(torch.stack(host_all).reshape(world, -1, args.tile, args.tile, 3), args.width, args.width, args.tile, world).numpy()
-        elif world > 1:
+            import numpy as np
+            img = np.zeros((args.width, args.width, 3), np.uint8)
+            for r, blob in enumerate(host_all):   # rank r's packed tiles: [local tile][row][col][rgb]
+                t = np.frombuffer(blob, np.uint8).reshape(-1, args.tile, args.tile, 3)
+                tx = (args.width + args.tile - 1) // args.tile
+                for lt in range(t.shape[0]):
+                    gt = lt * world + r
+                    if gt >= tx * tx:
+                        break
+                    y0, x0 = (gt // tx) * args.tile, (gt % tx) * args.tile
+                    h, w = min(args.tile, args.width - y0), min(args.tile, args.width - x0)
+                    img[y0:y0 + h, x0:x0 + w] = t[lt, :h, :w]
+        elif multi:
             img = frame[0].cpu().numpy()
         else:
             img = rt.untile(tiles[(args.steps - 1) % n_slots].to_host(), args.width, args.width, args.tile)
@@ -290,15 +339,29 @@ def main():
         achieved = traffic / (avg_launch_ms * 1e-3) / 1e9
         basis = "measured fabric reads behind L2 (PMC) per launch / launch time"
     else:
-        achieved = min(delivery, peak)
-        basis = "algorithmic record bytes / launch time, capped at the peak (no valid PMC traffic)"
+        achieved = None
+        basis = ("no valid PMC traffic for this kernel and workload: achieved / frac are not stated (record_delivery_GBps is the algorithmic rate -- "
+                 "records come from LDS, L1 and L2 too, it can exceed the peak)")
+    # what binds: the kernel issues VALU instructions for >= 90 % of its cycles (PMC: SQ_INSTS_VALU x 4 cycles / SIMD / kernel cycles) while
+    # the fabric carries a fraction of its peak -> "valu"; else the memory level the scene lives in
+    valu_share = (valu or {}).get("issue_cycles_over_kernel_cycles")
+    bound = "valu" if (valu_share or 0.0) >= 0.9 else ("mall" if in_mall else "hbm")
 
     def per_class(nbytes, rays, nodes, prims):
         return {"rays_per_step": int(rays), "algorithmic_bytes_per_step": int(nbytes), "bytes_per_ray": round(nbytes / max(rays, 1), 1),
                 "nodes_per_ray": round(nodes / max(rays, 1), 3), "prims_per_ray": round(prims / max(rays, 1), 3)}
 
-    roofline = {"bound": "hbm", "kernel": "path_kernel (closest-hit + shadow queries of all bounce levels, one persistent launch per batch)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(min(achieved / peak, 1.0), 5), "traffic": traffic,
+    if valu:  # lane-instructions: VALU instructions x the lanes that executed them
+        li = valu["insts_per_launch"] * 64.0 * valu["active_lane_fraction"]
+        valu = dict(valu, lane_instr_per_ray=round(li / max(t_rays / max(launches_per_step, 1), 1), 1),
+                    lane_instr_rate_T_per_s=round(li / (avg_launch_ms * 1e-3) / 1e12, 2) if avg_launch_ms > 0 else None,
+                    lane_instr_peak_T_per_s=round(256 * 4 * 64 / 4 * 2.4e9 / 1e12, 1),   # 1,024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
+                    note="issue_cycles_over_kernel_cycles counts 4 cycles per wave64 VALU instruction (one wave's issue cost); measured in "
+                         "round 3: 14 % fewer VALU instructions bought 5 % of the kernel's time, the waves wait 45 % of their life for loads "
+                         "(SQ_WAIT_ANY / SQ_WAVE_CYCLES): issue AND load latency at 5 waves per SIMD")
+    roofline = {"bound": bound, "kernel": "path_kernel (closest-hit + shadow queries of all bounce levels, one persistent launch per batch)",
+                "achieved": round(achieved, 2) if achieved is not None else None, "peak": peak, "unit": "GB/s",
+                "frac": round(achieved / peak, 5) if achieved is not None else None, "traffic": traffic,
                 "peak_is": ("random 128-byte gathers from L2 + Infinity Cache (scene %.0f MB <= 256 MB)" % (info.device_bytes / 2**20)) if in_mall
                            else "HBM3E (scene %.0f MB > Infinity Cache)" % (info.device_bytes / 2**20),
                 "frac_basis": basis, "pmc": pmc_note,
@@ -350,10 +413,13 @@ def main():
            "config": {"workload": f"{args.scene}: {scene_text}, {info.n_objects} primitives, "
                                   f"{args.width}x{args.width}, {args.spp} spp, {args.bounces} bounces",
                       "tile": args.tile, "parallelism": f"image tiles x{world}, scene replicated",
-                      "gather": None if world == 1 else ("rtx_gather_image (library RCCL communicator)" if lib_gather else
-                                                         "FALLBACK: tiles through the host over gloo (RCCL communicator unavailable)" if host_gather else
-                                                         f"torch.distributed {args.backend}"),
+                      "gather": None if not multi else (f"rtx_gather_image (library RCCL communicator): {comm_text}" if lib_gather else
+                                                        "FALLBACK (--allow-host-gather): tiles through the host over the rendezvous sockets (RCCL communicator unavailable)" if host_gather else
+                                                        f"torch.distributed {args.backend}"),
                       "frames_in_flight": n_slots,
+                      "one_frame_in_flight": None if one_frame is None else
+                          {"ms_per_step": round(one_frame / args.steps * 1e3, 3), "value": round(rays_step * args.steps / one_frame / 1e6, 2), "unit": "Mrays/s",
+                           "what": "the same K steps with ONE frame in flight: the time of a frame; `value` is the throughput of frames_in_flight frames in rotation"},
                       "rays_per_step": int(rays_step), "primary_samples_per_step": args.width * args.width * args.spp,
                       "bvh": {"internal_nodes": info.n_internal, "leaves": info.n_leaves, "depth": info.depth,
                               "build_s": round(info.build_seconds, 3), "flatten_s": round(info.flatten_seconds, 3),
@@ -362,7 +428,9 @@ def main():
            "mprimary_samples_per_s": round(args.width * args.width * args.spp * args.steps / elapsed / 1e6, 2),
            "two_slots": overlapped, "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if rdzv:
+        rdzv.close()
+    if dist:
         dist.destroy_process_group()
 
 

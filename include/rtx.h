@@ -218,6 +218,12 @@ int rtx_comm_unique_id(void *id_128_bytes);
 int rtx_comm_init(rtx_ctx *ctx, const void *id_128_bytes, int rank, int nranks);
 int rtx_comm_rank(rtx_ctx *ctx);
 int rtx_comm_size(rtx_ctx *ctx);
+/* Which collective library and HIP runtime this process has bound the library's symbols to: "RCCL <version>
+ * (<path of the shared object that ncclAllGather resolves to>); HIP runtime <version> (<path>)", NUL-terminated,
+ * truncated to `size`.  A process that loads another copy of these libraries first (a framework that bundles
+ * its own) runs rtx_gather_image on THAT copy: bench.py prints this string next to the gather it timed.  No
+ * counterpart in the reference.  ctx may be NULL. */
+int rtx_comm_info(rtx_ctx *ctx, char *buf, size_t size);
 uint64_t rtx_gather_bytes_per_rank(rtx_ctx *ctx, uint32_t tile);
 int rtx_gather_image(rtx_ctx *ctx, uint32_t slot, uint32_t tile, const void *d_tiles_rgb8, void *d_all_tiles,
                      void *d_image_rgb8_or_null);

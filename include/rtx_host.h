@@ -70,6 +70,26 @@ int rtx_host_bvh_digest(const rtx_scene_desc *desc, int threads, uint32_t *leaf_
  * with a non-zero value are traced by the `_ovh` kernels (exactness). */
 float rtx_scene_hit_overhang(const rtx_scene_desc *desc);
 
+/* The host's cgmath-order f32 matrix arithmetic (csrc/hostmath.h) behind one door, so that tests can pin it against
+ * the reference's own vectors (utils.rs:91-108 test_get_scaling, object.rs:379-407) and against float64: it builds
+ * every transform, camera and box that BOTH sides of a GPU-vs-oracle parity test are fed with.  Matrices are 16
+ * column-major f32.  `in` / `out` per op:
+ *   FROM_ANGLE_X/Y/Z        in: degrees (1)            out: Matrix4::from_angle_*(Deg(a))                 (16)
+ *   FROM_TRANSLATION        in: x y z                  out: Matrix4::from_translation                     (16)
+ *   FROM_NONUNIFORM_SCALE   in: x y z                  out: Matrix4::from_nonuniform_scale                (16)
+ *   MUL                     in: lhs (16), rhs (16)     out: lhs * rhs                                     (16)
+ *   INVERT                  in: m (16)                 out: m.invert() / inverse_transform()              (16); RTX_ERR_DEGENERATE if singular
+ *   LOOK_AT                 in: eye, center, up (9)    out: Matrix4::look_at (right-handed, camera.rs:19) (16)
+ *   AXIS_SCALING            in: m (16)                 out: utils::get_axis_scaling (utils.rs:33-44)      (3)
+ *   TRANSFORM_POINT         in: m (16), p (3)          out: Transform::transform_point                    (3)
+ *   TRANSFORM_VECTOR        in: m (16), v (3)          out: Transform::transform_vector                   (3)
+ *   OBJECT_BOX              in: type (as float: RTX_OBJ_*), 12 vertex floats, object_to_world (16)
+ *                                                      out: Object::get_bounding_box (object.rs:290-313): min (3), max (3) */
+enum { RTX_M4_FROM_ANGLE_X = 0, RTX_M4_FROM_ANGLE_Y, RTX_M4_FROM_ANGLE_Z, RTX_M4_FROM_TRANSLATION, RTX_M4_FROM_NONUNIFORM_SCALE,
+       RTX_M4_MUL, RTX_M4_INVERT, RTX_M4_LOOK_AT, RTX_M4_AXIS_SCALING, RTX_M4_TRANSFORM_POINT, RTX_M4_TRANSFORM_VECTOR,
+       RTX_M4_OBJECT_BOX };
+int rtx_host_m4(int op, const float *in, float *out);
+
 #ifdef __cplusplus
 }
 #endif

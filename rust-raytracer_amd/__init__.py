@@ -137,6 +137,7 @@ def lib():
     L.rtx_host_bvh_digest.argtypes = [C.POINTER(SceneDesc), C.c_int, _u32p, _u32p, _u32p, _f32p, _u32p]
     L.rtx_scene_hit_overhang.argtypes = [C.POINTER(SceneDesc)]
     L.rtx_scene_hit_overhang.restype = C.c_float
+    L.rtx_host_m4.argtypes = [C.c_int, _f32p, _f32p]
     _lib = L
     return L
 
@@ -309,6 +310,28 @@ class ArrayScene:
 def hit_overhang(scene):
     """rtx_scene_hit_overhang: how far a hit can lie outside its object's reference box (0 for most scenes)."""
     return float(lib().rtx_scene_hit_overhang(scene.desc))
+
+
+M4_OPS = {"from_angle_x": (0, 1, 16), "from_angle_y": (1, 1, 16), "from_angle_z": (2, 1, 16), "from_translation": (3, 3, 16),
+          "from_nonuniform_scale": (4, 3, 16), "mul": (5, 32, 16), "invert": (6, 16, 16), "look_at": (7, 9, 16),
+          "axis_scaling": (8, 16, 3), "transform_point": (9, 19, 3), "transform_vector": (10, 19, 3), "object_box": (11, 29, 6)}
+
+
+def host_m4(op, *args):
+    """rtx_host_m4: the host's cgmath-order f32 matrix arithmetic (csrc/hostmath.h).  Matrices go in and come out as
+    4x4 numpy arrays in mathematical layout (m[row, col]); the ABI's 16 floats are column-major."""
+    code, n_in, n_out = M4_OPS[op]
+    flat = []
+    for a in args:
+        a = np.asarray(a, np.float32)
+        flat.append(a.T.reshape(-1) if a.shape == (4, 4) else a.reshape(-1))
+    buf = np.ascontiguousarray(np.concatenate(flat), np.float32)
+    assert buf.size == n_in, (op, buf.size, n_in)
+    out = np.zeros(n_out, np.float32)
+    rc = lib().rtx_host_m4(code, _ptr(buf, _f32p), _ptr(out, _f32p))
+    if rc < 0:
+        raise RtxError(rc, f"rtx_host_m4({op})")
+    return out.reshape(4, 4).T.copy() if n_out == 16 else out
 
 
 def host_bvh_digest(scene, threads=8):
@@ -510,6 +533,17 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def comm_info():
+    """rtx_comm_info: the RCCL and HIP runtime this process has bound (version and resolved path of each)."""
+    buf = C.create_string_buffer(1024)
+    L = lib()
+    L.rtx_comm_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    rc = L.rtx_comm_info(None, buf, 1024)
+    if rc < 0:
+        raise RtxError(rc, "rtx_comm_info")
+    return buf.value.decode()
 
 
 def comm_unique_id():

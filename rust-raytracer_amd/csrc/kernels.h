@@ -83,6 +83,7 @@ struct Frame {
     uint32_t *work;     // WORK_WORDS queue heads
     uint32_t *spill;    // traversal-stack overflow, [spill entries][threads] of (ref, t)
     uint32_t node_cap, wstack_cap;
+    uint32_t stripe;    // entries of the queue of primaries that make one stripe (WaveQueue): 64 pixel slots x the batch's samples
 };
 
 struct BatchInfo {

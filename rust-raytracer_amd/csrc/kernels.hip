@@ -763,32 +763,59 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
 #endif
 struct WaveQueue {
     uint32_t *heads;
-    uint32_t count, chunk, psize, nwaves, p0, tried;
+    uint32_t count, chunk, stripe, nstripes, nwaves, p0, tried;
     uint32_t next, end;
     bool exhausted;
-    // Sub-queue p covers [p*psize, (p+1)*psize).  Its first waves_per_part*chunk entries
-    // are dealt statically (wave j of the sub-queue owns chunk j: no atomic at all for
-    // queues that small); the rest is handed out through the sub-queue's head counter.
-    // Statically dealt entries of sub-queue p: one chunk per wave that exists in it (wave j*QPARTS+p
-    // for j*QPARTS+p < nwaves) -- a chunk without an owner would never be traced.
-    __device__ __forceinline__ uint32_t dyn0_of(uint32_t p) const {
-        return p < nwaves ? ((nwaves - p + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS) * chunk : 0u;
+    // The queue of primaries is cut into stripes of `stripe` entries -- one 8x8 pixel block with all its samples
+    // (raygen) -- and stripe k belongs to sub-queue k % QPARTS: every sub-queue is a comb over the whole frame, all
+    // sub-queues cost the same and run dry together, and all of them are at the same place of the frame at the
+    // same time: the whole chip works on the same few tiles, so what one wave brings into the L2s and the
+    // Infinity Cache is there for the others.  (Measured, round 3, headline frame: stripes of 4 / 16 / 64 blocks
+    // 8.5 / 9.3 / 9.0 ms against 8.3; sub-queues as bands of the frame 9.3 ms; and the sub-queues dealt to the
+    // XCDs -- blocks b and b + 8 share one -- so that each XCD's L2 holds an eighth of what the frame sees: L2
+    // hit rate 0.55 -> 0.73, fabric reads -45 %, and the kernel 15 % SLOWER, its waves waiting longer for their
+    // loads than before.)
+    // A position in a sub-queue is a cursor c: stripe c / stripe of the comb, offset c % stripe in it.  A
+    // sub-queue's first entries are dealt statically (wave j of the sub-queue owns chunk j: no atomic at all for
+    // queues that small); the rest is handed out through the sub-queue's head counter (one hot counter sustains
+    // only ~90 atomics/us).  A chunk is 32 or 64 entries and divides the stripe, so a chunk never leaves its stripe.
+    // Waves whose first sub-queue is p: wave j * QPARTS + p for j * QPARTS + p < nwaves.
+    __device__ __forceinline__ uint32_t waves_of(uint32_t p) const {
+        return nwaves > p ? (nwaves - p + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS : 0u;
     }
-    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t nw, uint32_t wave) {
+    // Statically dealt entries of sub-queue p: one chunk per wave that exists in it -- a chunk without an owner
+    // would never be traced.
+    __device__ __forceinline__ uint32_t dyn0_of(uint32_t p) const { return waves_of(p) * chunk; }
+    // entries of sub-queue p: its stripes p, p + QPARTS, ...; the queue's last stripe may be short
+    __device__ __forceinline__ uint32_t len_of(uint32_t p) const {
+        if (p >= nstripes) return 0u;
+        const uint32_t k = (nstripes - p + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS;
+        const uint32_t cut = (nstripes - 1u) % (uint32_t)QPARTS == p ? nstripes * stripe - count : 0u;
+        return k * stripe - cut;
+    }
+    // the run [c, c + chunk) of sub-queue p (clipped to its length `len`), as queue entries [next, end)
+    __device__ __forceinline__ void set_run(uint32_t p, uint32_t c, uint32_t len) {
+        const uint32_t si = c / stripe, n = len - c < chunk ? len - c : chunk;
+        next = (si * (uint32_t)QPARTS + p) * stripe + (c - si * stripe);
+        end = next + n;
+    }
+    __device__ __forceinline__ void init(uint32_t *h, uint32_t n, uint32_t stripe_entries, uint32_t nw, uint32_t wave) {
         heads = h;
         count = n;
         nwaves = nw;
-        uint32_t c = n / (nwaves * 4u);
-        chunk = c < (uint32_t)RTX_CHUNK_MIN ? (uint32_t)RTX_CHUNK_MIN : (c > (uint32_t)RTX_CHUNK_MAX ? (uint32_t)RTX_CHUNK_MAX : c);
-        psize = ((n + (uint32_t)QPARTS - 1u) / (uint32_t)QPARTS + 63u) & ~63u;
+        stripe = stripe_entries >= 64u ? stripe_entries & ~63u : 64u;
+        nstripes = (n + stripe - 1u) / stripe;
+#ifdef RTX_CHUNK_FIXED
+        chunk = (uint32_t)RTX_CHUNK_FIXED;
+#else
+        chunk = n / (nwaves * 4u) < 48u ? 32u : 64u;
+#endif
         p0 = wave % (uint32_t)QPARTS;
         tried = 0;
         exhausted = n == 0;
-        uint32_t pb = p0 * psize, j = wave / (uint32_t)QPARTS;
-        uint32_t pe = pb + psize < n ? pb + psize : n;
-        next = pb + j * chunk;
-        end = next + chunk < pe ? next + chunk : pe;
-        if (pb >= n || next >= pe) next = end = 0;
+        next = end = 0;
+        const uint32_t c = (wave / (uint32_t)QPARTS) * chunk, len = len_of(p0);
+        if (c < len) set_run(p0, c, len);
     }
     // Gives every idle lane (ballot `idle`) its queue index; returns false for lanes left empty.
     __device__ __forceinline__ bool take(unsigned long long idle, bool lane_idle, uint32_t &index) {
@@ -798,11 +825,9 @@ struct WaveQueue {
                 next = end = 0;
                 return false;
             }
-            uint32_t p = (p0 + tried) % (uint32_t)QPARTS;
-            uint32_t pb = p * psize;
-            uint32_t pe = pb + psize < count ? pb + psize : count;
-            const uint32_t dyn0 = dyn0_of(p);
-            uint32_t dyn = (pb < count && pe - pb > dyn0) ? pe - pb - dyn0 : 0u;
+            const uint32_t p = (p0 + tried) % (uint32_t)QPARTS;
+            const uint32_t len = len_of(p), dyn0 = dyn0_of(p);
+            const uint32_t dyn = len > dyn0 ? len - dyn0 : 0u;
             uint32_t *hp = heads + p * (uint32_t)QHEAD_STRIDE;
             uint32_t b = dyn;
             if (dyn != 0u) {
@@ -814,8 +839,7 @@ struct WaveQueue {
                 tried++;
                 continue;
             }
-            next = pb + dyn0 + b;
-            end = next + chunk < pe ? next + chunk : pe;
+            set_run(p, dyn0 + b, len);
         }
         uint32_t avail = end - next, nidle = (uint32_t)__popcll(idle);
         uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
@@ -858,7 +882,10 @@ __global__ void __launch_bounds__(BLOCK) raygen_kernel(DeviceScene sc, Frame fr,
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) fr.counters[CTR_LEVEL_COUNT] = n;
     if (i >= n) return;
-    uint32_t q = i % bi.npix, sl = i / bi.npix;
+    // path node i = ((pixel block * ns) + sample) * 64 + slot in block: the samples of one 8x8 pixel block are
+    // neighbours in the queue of primaries: consecutive runs of a sub-queue are the same pixels again (WaveQueue),
+    // and the resolve pass finds a pixel's samples 64 nodes apart
+    const uint32_t blk = (i >> 6) / bi.ns, sl = (i >> 6) % bi.ns, q = blk * 64u + (i & 63u);
     uint32_t px, py, toff;
     bool valid = slot_to_pixel(bi, sc.width, sc.height, bi.q0 + q, px, py, toff);
     if (!valid) {
@@ -992,6 +1019,16 @@ __device__ __forceinline__ bool outside_cone(const LightRec &L, F3 point) {
     return outside;
 }
 
+#ifdef RTX_RAY_HIST
+// Diagnostic (-DRTX_RAY_HIST, COUNT launches, RTX_HIST_PRINT=1): records visited per ray, in powers of two, by
+// class -- 0 primary, 1 bounce, 2 point / cone shadow query, 3 directional shadow query, +4 for rays with an
+// ill-conditioned axis -- behind the counter block: [class][16] ray counts, then [class][16] record sums.
+__device__ __forceinline__ void ray_hist(uint32_t *ctr, uint32_t cls, uint32_t records) {
+    const uint32_t b = records ? min(15u, 32u - (uint32_t)__clz(records)) : 0u;
+    atomicAdd(ctr + CTR_WORDS + cls * 16u + b, 1u);
+    atomicAdd(ctr + CTR_WORDS + 128u + cls * 16u + b, records);
+}
+#endif
 template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK>
 __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
@@ -1032,14 +1069,21 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     for (uint32_t l = 0; l < sc.n_lights; l++) per_hit += sc.lights[l].type != LIGHT_AMBIENT ? 1u : 0u;
     uint32_t vis_cn = 0, vis_cp = 0, vis_sn = 0, vis_sp = 0, max_steps = 0;  // COUNT
     Util util;
+#ifdef RTX_WAVE_TIMES
+    // Diagnostic (-DRTX_WAVE_TIMES, RTX_WAVE_TIMES=1): when each wave began, found the queue dry and ended (100 MHz
+    // ticks), left in the last two entries of its shading list -- the production kernel otherwise, no other timers.
+    const uint32_t wt_begin = (uint32_t)wall_clock64();
+    uint32_t wt_dry = 0;
+#endif
     WaveQueue wq;
-    wq.init(fr.work, n0, nthreads / 64u, gtid / 64u);
+    wq.init(fr.work, n0, fr.stripe, nthreads / 64u, gtid / 64u);
     uint32_t refill_min = (uint32_t)RTX_REFILL_MIN, steps_run = 0;  // wave-uniform
     float end_rate = -1.0f;                                         // rays ending per step, running mean
 #ifdef RTX_UTIL_STATS
     const unsigned long long t_begin = wall_clock64();
     unsigned long long t_dry = 0;
     uint32_t dry_events = 0, dry_steps0 = 0, dry_fin = 0, dry_top = 0, dry_fin_c = 0;
+    unsigned long long dry_step_ticks0 = 0, dry_sec0[4] = {0, 0, 0, 0};
 #endif
     for (;;) {
         const bool idle = s.done();
@@ -1048,6 +1092,9 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         const uint32_t nidle = (uint32_t)__popcll(idlem), nfin = (uint32_t)__popcll(finm), nact = 64u - nidle;
         const uint32_t avail = top + shn + (wq.exhausted ? 0u : 64u);
         if (nact == 0u && nfin == 0u && avail == 0u) break;
+#ifdef RTX_WAVE_TIMES
+        if (wq.exhausted && wt_dry == 0u) wt_dry = (uint32_t)wall_clock64() | 1u;
+#endif
         // lanes between rays are handled together once enough of them wait: a quarter of the
         // wave (of what is left of it once the queue of primaries is dry)
         const uint32_t serve = nidle < avail ? nidle : avail;
@@ -1091,6 +1138,8 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         if (wq.exhausted && t_dry == 0) {
             t_dry = wall_clock64();
             dry_steps0 = util.node_steps + util.prim_steps;
+            dry_step_ticks0 = util.step_ticks;
+            for (int k = 0; k < 4; k++) dry_sec0[k] = util.sec_ticks[k];
             dry_top = top + shn + nact;
         }
         if (t_dry) {
@@ -1113,6 +1162,9 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 const bool reaches = (tag & WK_DIR) ? !s.any : (s.any && !s.occluded);
                 if (reaches) atomicOr(&fr.link[node].x, 1u << (tag & WK_LIGHT));
                 if (COUNT) {
+#ifdef RTX_RAY_HIST
+                    ray_hist(fr.counters, 2u + ((tag & WK_DIR) ? 1u : 0u) + (s.r.ill_any() || s.r.exact_only ? 4u : 0u), s.nodes + s.prims);
+#endif
                     vis_sn += s.nodes;
                     vis_sp += s.prims;
                     max_steps = max(max_steps, s.nodes + s.prims);
@@ -1124,6 +1176,9 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 fr.ray_o[node].w = s.any ? s.t : 0.0f;
                 fr.ray_d[node].w = __uint_as_float(s.prim);
                 if (COUNT) {
+#ifdef RTX_RAY_HIST
+                    ray_hist(fr.counters, ((tag >> WK_LEVEL_SHIFT) ? 1u : 0u) + (s.r.ill_any() || s.r.exact_only ? 4u : 0u), s.nodes + s.prims);
+#endif
                     vis_cn += s.nodes;
                     vis_cp += s.prims;
                     max_steps = max(max_steps, s.nodes + s.prims);
@@ -1314,6 +1369,12 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             RTX_SECTION(3)
         }
     }
+#ifdef RTX_WAVE_TIMES
+    if (SHADE && lane == 0) {
+        wsh[SHADE_LIST - 2] = make_uint2(wt_begin, wt_dry);
+        wsh[SHADE_LIST - 1] = make_uint2((uint32_t)wall_clock64(), 0x57415645u);
+    }
+#endif
     // what is left of the wave's last run of pool nodes
     if constexpr (SHADE) {
         for (uint32_t h = run_next + lane; h < run_end; h += 64u)
@@ -1336,8 +1397,12 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         if (t_dry && t_end - t_dry > 60000ull) {  // > 0.6 ms after the queue ran dry: a straggler, listed behind the counters
             uint32_t *dbg = fr.counters + CTR_WORDS;
             const uint32_t k = atomicAdd(dbg, 1u);
-            if (k < 40u) {
-                uint32_t *r = dbg + 1 + 6 * k;
+            if (k < 24u) {
+                uint32_t *r = dbg + 1 + 10 * k;
+                r[6] = (uint32_t)(util.step_ticks - dry_step_ticks0);
+                r[7] = (uint32_t)(util.sec_ticks[0] - dry_sec0[0]) + (uint32_t)(util.sec_ticks[2] - dry_sec0[2]);
+                r[8] = (uint32_t)(util.sec_ticks[1] - dry_sec0[1]);
+                r[9] = (uint32_t)(util.sec_ticks[3] - dry_sec0[3]);
                 r[0] = (uint32_t)(t_end - t_dry);
                 r[1] = dry_events;
                 r[2] = util.node_steps + util.prim_steps - dry_steps0;
@@ -1560,7 +1625,7 @@ __global__ void __launch_bounds__(BLOCK) accumulate_kernel(DeviceScene sc, Frame
     uint32_t lp = bi.q0 + q;
     float4 a = (bi.s0 == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : sum[lp];
     for (uint32_t sl = 0; sl < bi.ns; sl++) {  // fold in sample order (world.rs:54-61)
-        float4 c = fr.color[(size_t)sl * bi.npix + q];
+        float4 c = fr.color[((size_t)(q >> 6) * bi.ns + sl) * 64u + (q & 63u)];  // (raygen: node order)
         a.x = a.x + c.x;
         a.y = a.y + c.y;
         a.z = a.z + c.z;

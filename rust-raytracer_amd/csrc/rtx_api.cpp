@@ -1,5 +1,7 @@
 // C ABI of include/rtx.h: context, scene upload, wavefront render driver.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -17,6 +19,7 @@
 #include "../../include/rtx_host.h"
 #include "bvh_build.h"
 #include "flatten.h"
+#include "hostmath.h"
 #include "kernels.h"
 
 using namespace rtx;
@@ -87,6 +90,7 @@ struct rtx_ctx {
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
     uint32_t *h_noalloc_flag = nullptr;  // pinned word: CTR_OVERFLOW of the last rtx_render_device_noalloc (allocated by rtx_init)
     bool noalloc_pending = false;     // ... which nobody has looked at yet (rtx_synchronize / rtx_slot_synchronize(0) do)
+    uint32_t stripe_blocks = 1;       // RTX_STRIPE_BLOCKS: 8x8 pixel blocks (with all their samples) per stripe of the queue of primaries
     long test_pool_nodes = -1;        // RTX_TEST_POOL_NODES: tests shrink the pool of bounce children to force the overflow report
 };
 
@@ -264,6 +268,8 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
 int reset_counters(rtx_ctx *c, Pipe &pp) {
     static const bool util_print = std::getenv("RTX_UTIL_PRINT") != nullptr;  // diagnostic builds (-DRTX_UTIL_STATS)
     HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, (WORK_WORDS + CTR_WORDS) * sizeof(uint32_t), pp.main));
+    static const bool hist_print = std::getenv("RTX_HIST_PRINT") != nullptr;
+    if (hist_print && pp.allocs.size()) HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_WORDS, 0, 256 * sizeof(uint32_t), pp.main));
     if (util_print) {
         if (pp.allocs.size()) HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_WORDS, 0, 256 * sizeof(uint32_t), pp.main));
         HIP_TRY(c, hipMemsetAsync(pp.fr.counters + CTR_UTIL + 20, 0xFF, 8, pp.main));  // earliest wave begin: atomicMin
@@ -365,6 +371,47 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
         stats->shadow_nodes += (uint64_t)h[CTR_SVISIT_NODES_LO] | ((uint64_t)h[CTR_SVISIT_NODES_HI] << 32);
         stats->shadow_prims += (uint64_t)h[CTR_SVISIT_PRIMS_LO] | ((uint64_t)h[CTR_SVISIT_PRIMS_HI] << 32);
         stats->max_ray_records = std::max(stats->max_ray_records, h[CTR_MAX_STEPS]);
+        if (std::getenv("RTX_WAVE_TIMES") && pp.allocs.size() && bi + 1 == nb) {  // diagnostic builds (-DRTX_WAVE_TIMES)
+            const size_t per_wave = (size_t)pp.wstack_cap + SHADE_LIST, waves = (size_t)c->persistent_blocks * 4;
+            std::vector<uint2> w(waves * per_wave);
+            if (hipMemcpy(w.data(), pp.fr.wstack, w.size() * sizeof(uint2), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::vector<double> dry, end;
+                uint32_t t0 = 0;
+                bool have = false;
+                for (size_t k = 0; k < waves; k++) {
+                    const uint2 a = w[k * per_wave + per_wave - 2], b = w[k * per_wave + per_wave - 1];
+                    if (b.y != 0x57415645u) continue;
+                    if (!have || (int32_t)(a.x - t0) < 0) t0 = a.x;
+                    have = true;
+                }
+                for (size_t k = 0; k < waves; k++) {
+                    const uint2 a = w[k * per_wave + per_wave - 2], b = w[k * per_wave + per_wave - 1];
+                    if (b.y != 0x57415645u) continue;
+                    end.push_back((double)(uint32_t)(b.x - t0) * 1e-5);
+                    dry.push_back(a.y ? (double)(uint32_t)(a.y - t0) * 1e-5 : end.back());
+                }
+                std::sort(dry.begin(), dry.end());
+                std::sort(end.begin(), end.end());
+                auto q = [](const std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+                std::fprintf(stderr, "wave times (ms after the first wave began), %zu waves: queue dry at min %.3f / 10%% %.3f / median %.3f / 90%% %.3f / max %.3f; "
+                                     "ended at min %.3f / 10%% %.3f / median %.3f / 90%% %.3f / 99%% %.3f / max %.3f\n",
+                             end.size(), q(dry, 0), q(dry, 0.1), q(dry, 0.5), q(dry, 0.9), q(dry, 1.0), q(end, 0), q(end, 0.1), q(end, 0.5), q(end, 0.9),
+                             q(end, 0.99), q(end, 1.0));
+            }
+        }
+        if (std::getenv("RTX_HIST_PRINT") && pp.allocs.size()) {  // diagnostic builds (-DRTX_RAY_HIST), COUNT launches
+            uint32_t hist[256];
+            if (hipMemcpy(hist, pp.fr.counters + CTR_WORDS, sizeof hist, hipMemcpyDeviceToHost) == hipSuccess) {
+                static const char *names[8] = {"primary", "bounce", "shadow (point/cone)", "shadow (directional)", "primary, ill axis",
+                                               "bounce, ill axis", "shadow (point/cone), ill axis", "shadow (directional), ill axis"};
+                for (int cl = 0; cl < 8; cl++) {
+                    std::fprintf(stderr, "hist %-32s", names[cl]);
+                    for (int b = 0; b < 16; b++)
+                        if (hist[cl * 16 + b]) std::fprintf(stderr, " <%u: %u rays %u rec |", 1u << b, hist[cl * 16 + b], hist[128 + cl * 16 + b]);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+        }
         if (std::getenv("RTX_UTIL_PRINT")) {  // diagnostic builds (-DRTX_UTIL_STATS) fill these words
             const uint64_t *u = reinterpret_cast<const uint64_t *>(&h[CTR_UTIL]);
             std::fprintf(stderr, "util path node_steps %llu prim_steps %llu node_lanes %llu prim_lanes %llu done_lanes %llu "
@@ -377,9 +424,12 @@ int slot_stats(rtx_ctx *c, Pipe &pp, rtx_stats *stats) {
             uint32_t dbg[256];
             if (pp.allocs.size() && hipMemcpy(dbg, pp.fr.counters + CTR_WORDS, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 std::fprintf(stderr, "util stragglers (> 0.6 ms after the queue ran dry): %u\n", dbg[0]);
-                for (uint32_t k = 0; k < std::min(dbg[0], 40u); k++)
-                    std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry\n",
-                                 dbg[1 + 6 * k] * 1e-5, dbg[2 + 6 * k], dbg[3 + 6 * k], dbg[4 + 6 * k], dbg[6 + 6 * k], dbg[5 + 6 * k]);
+                for (uint32_t k = 0; k < std::min(dbg[0], 24u); k++) {
+                    const uint32_t *r = dbg + 1 + 10 * k;
+                    std::fprintf(stderr, "   %.3f ms: %u events, %u wave steps, %u rays finished (%u closest), %u entries + rays held when dry; "
+                                         "of it %.3f ms in steps, %.3f finished rays + stack/queue, %.3f shading pass, %.3f ray begin\n",
+                                 r[0] * 1e-5, r[1], r[2], r[3], r[5], r[4], r[6] * 1e-5, r[7] * 1e-5, r[8] * 1e-5, r[9] * 1e-5);
+                }
             }
             std::fprintf(stderr, "util waves: kernel %.3f ms, mean wave lifetime %.3f ms (%.3f ms of it in traversal steps), mean / max time after the queue ran dry %.3f / %.3f ms\n",
                          (double)(u[11] - u[10]) * 1e-5, (double)u[12] * 1e-5 / (c->persistent_blocks * 4.0),
@@ -528,6 +578,7 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
             lc.persistent_blocks = c->blocks_fixed ? c->persistent_blocks
                                                    : (int)std::min<uint64_t>((uint64_t)c->persistent_blocks,
                                                                              std::max<uint64_t>(256, (uint64_t)b.npix * b.ns / 1024));
+            lane.fr.stripe = 64u * c->stripe_blocks * std::min(b.ns, 4096u);
             launch_raygen(c->ds, lane.fr, info, lc);
             rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi);
             if (rc != RTX_OK) return rc;
@@ -609,6 +660,7 @@ int rtx_init(int device, rtx_ctx **out) {
     }
     c->stream = c->pipes[0].main;
     c->persistent_blocks = query_persistent_blocks(device);
+    if (std::getenv("RTX_VERBOSE")) std::fprintf(stderr, "rtx_init: device %d, persistent grid %d blocks of 256 threads\n", device, c->persistent_blocks);
     if (const char *pb = std::getenv("RTX_PERSISTENT_BLOCKS"))  // tests: grids whose wave count is not a multiple of QPARTS
         if (std::atoi(pb) > 0) {
             c->persistent_blocks = std::atoi(pb);
@@ -628,6 +680,7 @@ int rtx_init(int device, rtx_ctx **out) {
         return RTX_ERR_HIP;
     }
     *c->h_noalloc_flag = 0;
+    if (const char *sb = std::getenv("RTX_STRIPE_BLOCKS")) c->stripe_blocks = (uint32_t)std::min(1024, std::max(1, std::atoi(sb)));
     if (const char *tp = std::getenv("RTX_TEST_POOL_NODES")) c->test_pool_nodes = std::max(0L, std::atol(tp));
     if (const char *lb = std::getenv("RTX_LEAF_BANK")) c->leaf_bank = std::atoi(lb) != 0;
     if (const char *bl = std::getenv("RTX_BATCH_LANES")) c->batch_lanes = std::atoi(bl);
@@ -895,6 +948,7 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     // the array keeps the previous call's contents: counters and queue heads must start at zero
     rc = reset_counters(c, np);
     if (rc != RTX_OK) return rc;
+    np.fr.stripe = 64u * c->stripe_blocks * std::min(spp, 4096u);
     launch_raygen(c->ds, np.fr, info, lc);
     rc = run_path(c, np, np.events, lc, levels, false, 0);
     if (rc != RTX_OK) return rc;
@@ -977,6 +1031,21 @@ int rtx_comm_init(rtx_ctx *c, const void *id_128_bytes, int rank, int nranks) {
     NCCL_TRY(c, ncclCommInitRank(&c->comm, nranks, id, rank));
     c->comm_rank = rank;
     c->comm_size = nranks;
+    return RTX_OK;
+}
+
+int rtx_comm_info(rtx_ctx *, char *buf, size_t size) {
+    if (!buf || size == 0) return RTX_ERR_INVALID;
+    int nv = 0, hv = 0;
+    (void)ncclGetVersion(&nv);
+    (void)hipRuntimeGetVersion(&hv);
+    Dl_info dn{}, dh{};
+    const char *pn = dladdr(reinterpret_cast<void *>(&ncclAllGather), &dn) && dn.dli_fname ? dn.dli_fname : "?";
+    const char *ph = dladdr(reinterpret_cast<void *>(&hipStreamSynchronize), &dh) && dh.dli_fname ? dh.dli_fname : "?";
+    char real_n[PATH_MAX], real_h[PATH_MAX];
+    if (realpath(pn, real_n)) pn = real_n;
+    if (realpath(ph, real_h)) ph = real_h;
+    std::snprintf(buf, size, "RCCL %d.%d.%d (%s); HIP runtime %d (%s)", nv / 10000, (nv / 100) % 100, nv % 100, pn, hv, ph);
     return RTX_OK;
 }
 
@@ -1076,6 +1145,7 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
         info.tiles_y = pt.tiles_y;
         info.max_levels = 1;
         (void)reset_counters(c, pp);
+        pp.fr.stripe = 64u;
         launch_raygen(c->ds, pp.fr, info, lc);
         launch_path(c->ds, pp.fr, 1, false, lc);
         launch_export_hits(c->ds, pp.fr, n, d_obj, d_t, lc);
@@ -1128,6 +1198,7 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
         uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - i0);
         hipError_t e = hipMemcpyAsync(d_rays, org_dir + i0 * 6, (size_t)m * 24, hipMemcpyHostToDevice, c->stream);
         (void)reset_counters(c, pp);
+        pp.fr.stripe = 64u;
         launch_load_rays(pp.fr, d_rays, m, lc);
         if (out_rgb) {
             if (run_path(c, pp, pp.events, lc, levels, false, 0) != RTX_OK) e = hipErrorUnknown;
@@ -1181,6 +1252,61 @@ int rtx_host_bvh_digest(const rtx_scene_desc *d, int threads, uint32_t *leaf_ord
     if (total_sa) *total_sa = fs.total_sa;
     if (n_internal) *n_internal = (uint32_t)fs.nodes.size();
     return (int)fs.preorder_sizes.size();
+}
+
+int rtx_host_m4(int op, const float *in, float *out) {
+    if (!in || !out) return RTX_ERR_INVALID;
+    auto put = [&](const M4 &m) { std::memcpy(out, m.m, sizeof(m.m)); };
+    auto get = [&](const float *p) {
+        M4 m;
+        std::memcpy(m.m, p, sizeof(m.m));
+        return m;
+    };
+    auto put3 = [&](V3 v) {
+        out[0] = v.x;
+        out[1] = v.y;
+        out[2] = v.z;
+    };
+    switch (op) {
+        case RTX_M4_FROM_ANGLE_X: put(m4_from_angle_x(in[0])); return RTX_OK;
+        case RTX_M4_FROM_ANGLE_Y: put(m4_from_angle_y(in[0])); return RTX_OK;
+        case RTX_M4_FROM_ANGLE_Z: put(m4_from_angle_z(in[0])); return RTX_OK;
+        case RTX_M4_FROM_TRANSLATION: put(m4_from_translation(v3(in[0], in[1], in[2]))); return RTX_OK;
+        case RTX_M4_FROM_NONUNIFORM_SCALE: put(m4_from_nonuniform_scale(in[0], in[1], in[2])); return RTX_OK;
+        case RTX_M4_MUL: put(get(in) * get(in + 16)); return RTX_OK;
+        case RTX_M4_INVERT: {
+            M4 r;
+            if (!m4_invert(get(in), r)) return RTX_ERR_DEGENERATE;
+            put(r);
+            return RTX_OK;
+        }
+        case RTX_M4_LOOK_AT: put(m4_look_at(v3(in[0], in[1], in[2]), v3(in[3], in[4], in[5]), v3(in[6], in[7], in[8]))); return RTX_OK;
+        case RTX_M4_AXIS_SCALING: {
+            const M4 m = get(in);
+            put3(v3(magnitude(transform_vector(m, v3(1, 0, 0))), magnitude(transform_vector(m, v3(0, 1, 0))),
+                    magnitude(transform_vector(m, v3(0, 0, 1)))));
+            return RTX_OK;
+        }
+        case RTX_M4_TRANSFORM_POINT: put3(transform_point(get(in), v3(in[16], in[17], in[18]))); return RTX_OK;
+        case RTX_M4_TRANSFORM_VECTOR: put3(transform_vector(get(in), v3(in[16], in[17], in[18]))); return RTX_OK;
+        case RTX_M4_OBJECT_BOX: {  // the builder's own box routine on a one-object description
+            const int32_t type = (int32_t)in[0], zero = 0;
+            if (type < 0 || type > 2) return RTX_ERR_INVALID;
+            float xf[32];
+            std::memcpy(xf, in + 13, 16 * sizeof(float));
+            std::memset(xf + 16, 0, 16 * sizeof(float));  // (world_to_object is not looked at by the box)
+            rtx_scene_desc d{};
+            d.n_objects = 1;
+            d.obj_type = &type;
+            d.obj_verts = in + 1;
+            d.obj_xform = &zero;
+            d.n_xforms = 1;
+            d.xforms = xf;
+            object_bounding_box(d, 0, out, out + 3);
+            return RTX_OK;
+        }
+        default: return RTX_ERR_INVALID;
+    }
 }
 
 float rtx_scene_hit_overhang(const rtx_scene_desc *d) {

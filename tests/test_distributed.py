@@ -60,3 +60,38 @@ def test_assemble_single_rank_roundtrip():
     for n in (1, 2, 3):
         packs = torch.stack([tl.pack_region(img, 16, r, n) for r in range(n)])
         assert torch.equal(tl.assemble(packs, 70, 70, 16, n), img)
+
+
+# ---------------------------------------------------------------- bench.py's host-side rendezvous (no torch, no GPU)
+def _rdzv_worker(rank, world, path, out_dir):
+    sys.path.insert(0, ROOT)
+    rv = importlib.import_module("rust-raytracer_amd.rendezvous").Rendezvous(rank, world, timeout=30.0, path=path)
+    got = rv.broadcast(("id-" + "ab" * 64) if rank == 0 else None)          # the RCCL id's way: hex of 128 bytes
+    ranks = rv.allgather([rank, 1.5 * rank])
+    rv.barrier()
+    blobs = rv.allgather_bytes(bytes([rank]) * (1000 + rank))              # --allow-host-gather: ragged byte strings
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write(repr((got, ranks, [len(b) for b in blobs], [b[0] for b in blobs])))
+    rv.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rendezvous_star(tmp_path, world):
+    """The TCP star that carries bench.py's RCCL id, barriers and reductions at N > 1 (world size 2 and 3, CPU)."""
+    path = str(tmp_path / "rdzv")
+    mp.spawn(_rdzv_worker, args=(world, path, str(tmp_path)), nprocs=world, join=True)
+    want = repr(("id-" + "ab" * 64, [[r, 1.5 * r] for r in range(world)], [1000 + r for r in range(world)], list(range(world))))
+    for r in range(world):
+        assert (tmp_path / f"r{r}.txt").read_text() == want
+    assert not os.path.exists(path)   # rank 0 removes the rendezvous file
+
+
+def test_bench_multi_rank_path_does_not_import_torch():
+    """bench.py's default N > 1 path must not pull torch (and with it torch's bundled RCCL / HIP runtime) into the process."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("    elif multi:\n        import torch")]
+    assert "import torch" not in head
+    rsrc = open(os.path.join(ROOT, "rust-raytracer_amd", "rendezvous.py")).read()
+    assert "import torch" not in rsrc
+    binding = open(os.path.join(ROOT, "rust-raytracer_amd", "__init__.py")).read()
+    assert "import torch" not in binding

@@ -66,3 +66,55 @@ def test_gather_without_communicator_fails(rt, gpu):
     with pytest.raises(rt.RtxError) as e:
         gpu.gather_image(b.ptr, b.ptr)
     assert e.value.status == rt.RTX_ERR_COMM
+
+
+def _run_bench(args, env_extra=None, timeout=170):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_comm_info_names_the_linked_runtime(rt):
+    """The library's RCCL and HIP runtime are the ones it is linked against (/opt/rocm), in this process."""
+    info = rt.comm_info()
+    assert info.startswith("RCCL ") and "HIP runtime" in info
+    assert info.count("/opt/rocm") == 2, info
+
+
+def test_bench_n_rank_path_runs_on_the_linked_rccl():
+    """bench.py's own N-rank code path (rendezvous, rtx_comm_init, render + rtx_gather_image per step, the reductions)
+    driven with a communicator of one rank: the process must not have torch's bundled runtime underneath it."""
+    rc, line, err = _run_bench(["--gpus", "1", "--force-comm", "--scene", "basic_suzanne", "--width", "256", "--spp", "2", "--steps", "3",
+                                "--warmup", "1", "--no-cpu-baseline", "--no-reference-visits"])
+    assert rc == 0, err[-2000:]
+    g = line["config"]["gather"]
+    assert g.startswith("rtx_gather_image (library RCCL communicator)"), g
+    assert g.count("/opt/rocm") == 2 and "torch" not in g, g
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["frames_in_flight"] == 1
+
+
+def test_bench_fails_loudly_without_a_communicator():
+    """Two ranks on ONE device: RCCL refuses the duplicate GPU.  The default is to fail (a host gather must not pass for an
+    RCCL curve); --allow-host-gather runs, and the line says what it measured."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--one-device", "--scene", "basic",
+            "--width", "128", "--spp", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-reference-visits"]
+    p = subprocess.run(base, capture_output=True, text=True, timeout=170)
+    assert p.returncode != 0, p.stdout[-500:]
+    assert "RCCL communicator unavailable" in p.stderr
+    p = subprocess.run(base + ["--allow-host-gather"], capture_output=True, text=True, timeout=170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["gather"].startswith("FALLBACK"), line["config"]["gather"]
+    assert line["n_gpus"] == 2 and line["config"]["one_frame_in_flight"]["value"] > 0

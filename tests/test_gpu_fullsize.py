@@ -134,3 +134,65 @@ def test_soup_2M_vs_oracle(rt, orc, gpu):
     assert close >= 0.999, close
     assert st.rays == st_o.primary_rays + st_o.bounce_rays + st_o.shadow_rays
     o.close()
+
+
+def test_config4_at_its_stated_size(rt, orc, gpu):
+    """BASELINE configs[3] as stated: the 2.37 M-triangle geometry with mirror + glass + Phong compositions, 4096^2,
+    64 spp, 4 bounces -- 64 batches alternating between the slot's two lanes.  The production traversal and the
+    on-device verbatim bvh.rs:359-395 must produce the same bytes and count the same rays; the oracle traces a
+    stated subset of the frame (six 32x32 tiles: silhouettes of the meshes, the floor, the background) at all 64 samples."""
+    W = 4096
+    s = rt.HostScene("scan_glass", W, 0)
+    info = gpu.upload(s)
+    assert info.n_objects == 2374530
+    img, st = gpu.render(spp=64, bounces=4, seed=1)
+    assert st.batches == 64 and st.primary_rays == W * W * 64
+    assert st.bounce_rays > 0.25 * st.primary_rays and st.shadow_rays > st.primary_rays
+    img_r, st_r = gpu.render(spp=64, bounces=4, seed=1, flags=rt.FLAG_REFERENCE_TRAVERSAL)
+    assert np.array_equal(img, img_r), f"{(img != img_r).any(axis=2).sum()} pixels differ between the production and the verbatim traversal"
+    assert (st.primary_rays, st.bounce_rays, st.shadow_rays) == (st_r.primary_rays, st_r.bounce_rays, st_r.shadow_rays)
+    del img_r
+    o = orc.Scene(s)
+    checked = 0
+    for tx, ty in [(40, 60), (64, 70), (75, 66), (88, 72), (64, 120), (3, 3)]:   # tile column, tile row of the 128 x 128 tiles
+        x0, y0 = tx * 32, ty * 32
+        img_o, _ = o.render(spp=64, bounces=4, seed=1, threads=16, region=(x0, x0 + 32, 1, y0, y0 + 32, 1))
+        a, b = img[y0:y0 + 32, x0:x0 + 32].astype(int), img_o[y0:y0 + 32, x0:x0 + 32].astype(int)
+        close = (np.abs(a - b).max(axis=2) <= 1).mean()
+        assert close >= 0.999, (tx, ty, close)
+        checked += 1
+    assert checked == 6
+    o.close()
+
+
+def test_config5_at_its_stated_size(rt, gpu, monkeypatch):
+    """BASELINE configs[4] as stated: 20,000,000 random triangles, 2048^2, 16 spp, 4 point lights + ambient.  Size-independent
+    properties (the oracle's sequential builder does not get this far): every primary hit spawns exactly 4 shadow queries
+    and nothing bounces; the leaf-banking kernel the host picks for scenes this size and the default kernel produce the
+    same bytes; the verbatim traversal produces the same bytes on rank 3's tiles of a 16-way partition."""
+    W = 2048
+    s = rt.HostScene("soup", W, 0)
+    info = gpu.upload(s)
+    assert info.n_objects == 20000000
+    img, st = gpu.render(spp=16, bounces=4, seed=1)
+    assert st.primary_rays == W * W * 16 and st.bounce_rays == 0
+    hits = 0
+    for k in range(16):   # the primary rays of the 16 jittered samples, one by one
+        obj, _ = gpu.trace_primary(sample=k, use_jitter=True, seed=1)
+        hits += int((obj != 0xFFFFFFFF).sum())
+    assert st.shadow_rays == 4 * hits, (st.shadow_rays, hits)
+    part = (64, 3, 16)
+    a, sa = gpu.render(spp=16, bounces=4, seed=1, part=part)
+    b, sb = gpu.render(spp=16, bounces=4, seed=1, part=part, flags=rt.FLAG_REFERENCE_TRAVERSAL)
+    assert np.array_equal(a, b) and sa.rays == sb.rays
+    mine = a.any(axis=2)
+    assert mine.mean() > 0.03 and np.array_equal(a[mine], img[mine])   # the share is the frame's own pixels
+    del a, b
+    monkeypatch.setenv("RTX_LEAF_BANK", "0")    # read by rtx_init: this context runs the kernel without leaf banking
+    c2 = rt.Context(0)
+    try:
+        c2.upload(s)
+        img2, st2 = c2.render(spp=16, bounces=4, seed=1)
+        assert np.array_equal(img2, img) and st2.rays == st.rays
+    finally:
+        c2.close()

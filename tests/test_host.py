@@ -4,6 +4,7 @@ the on-disk formats decode, and the oracle still matches its committed golden ve
 import ctypes
 import hashlib
 import json
+import math
 import os
 import re
 import sys
@@ -520,3 +521,97 @@ def test_reference_patch_applies(tmp_path):
     world = (work / "src" / "world.rs").read_text()
     assert "rtx_upload_scene(ctx, &desc)" in world and "ThreadPool::new" not in world
     assert "pub(crate) object_type" in (work / "src" / "object.rs").read_text()
+
+
+# ---------------------------------------------------------------- host matrix arithmetic (csrc/hostmath.h via rtx_host_m4)
+# Every transform, camera and box that a GPU-vs-oracle parity test feeds to BOTH sides is built by this code, so it is
+# pinned on its own: against the reference's own vectors, restated through the host's builders (not numpy), and
+# against float64.
+
+def _m4(rt, op, *a):
+    return rt.host_m4(op, *a)
+
+
+def test_hostmath_reference_get_scaling(rt):  # utils.rs:91-108, test_get_scaling, through the host's own builders
+    rotate = _m4(rt, "mul", _m4(rt, "mul", _m4(rt, "from_angle_x", [120.0]), _m4(rt, "from_angle_y", [90.0])),
+                 _m4(rt, "from_angle_z", [45.0]))
+    translate = _m4(rt, "from_translation", [1.0, 0.5, -2.0])
+    np.testing.assert_allclose(_m4(rt, "axis_scaling", _m4(rt, "mul", rotate, translate)), (1, 1, 1), atol=1e-6)
+    scale = _m4(rt, "from_nonuniform_scale", [1.0, 2.0, 3.0])
+    inv_t = _m4(rt, "invert", translate)                       # translate.inverse_transform().unwrap()
+    m = _m4(rt, "mul", _m4(rt, "mul", _m4(rt, "mul", translate, rotate), scale), inv_t)
+    np.testing.assert_allclose(_m4(rt, "axis_scaling", m), (1, 2, 3), atol=1e-5)   # approx's default epsilon is f32::EPSILON-relative; 1e-5 abs is tighter than the values' own rounding allows to fail
+    np.testing.assert_allclose(_m4(rt, "axis_scaling", _m4(rt, "from_nonuniform_scale", [10.0, -0.5, 1.0])), (10, 0.5, 1), atol=0)
+
+
+def test_hostmath_reference_bounding_boxes(rt):  # object.rs:379-407 (identity transform), epsilon 1e-4 as there
+    eye = np.eye(4, dtype=np.float32)
+    box = _m4(rt, "object_box", [0.0], [2.0, 0.0, 1.0, 1.5] + [0.0] * 8, eye)     # 0 = RTX_OBJ_SPHERE: centre, radius
+    assert np.linalg.norm(box[:3] - (0.5, -1.5, -0.5)) < 1e-4 and np.linalg.norm(box[3:] - (3.5, 1.5, 2.5)) < 1e-4
+    quad = [1.0, 1.0, 1.0, 3.0, 1.0, 1.0, 3.0, 1.0, 0.0, 1.0, 1.0, 0.0]
+    box = _m4(rt, "object_box", [2.0], quad, eye)                                   # 2 = RTX_OBJ_QUAD
+    assert np.linalg.norm(box[:3] - (1.0, 1.0, 0.0)) < 1e-4 and np.linalg.norm(box[3:] - (3.0, 1.0, 1.0)) < 1e-4
+
+
+def _rot64(axis, deg):
+    c, s = math.cos(math.radians(deg)), math.sin(math.radians(deg))
+    m = np.eye(4)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[axis]
+    m[i, i], m[j, j], m[j, i], m[i, j] = c, c, s, -s          # right-handed rotation about `axis`
+    return m
+
+
+def _look_at64(eye, center, up):  # cgmath Matrix4::look_at (RH): rows (s, u, -f), translation (-eye.s, -eye.u, eye.f)
+    eye, center, up = (np.asarray(v, np.float64) for v in (eye, center, up))
+    f = (center - eye) / np.linalg.norm(center - eye)
+    s = np.cross(f, up)
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    m = np.eye(4)
+    m[0, :3], m[1, :3], m[2, :3] = s, u, -f
+    m[:3, 3] = (-eye @ s, -eye @ u, eye @ f)
+    return m
+
+
+def test_hostmath_against_float64(rt):
+    """The builders against float64 numpy at 1e-6: rotations, the three scene transforms (scene.rs:35-38, 194-199),
+    default_camera's look_at and its inverse (scene.rs:218-226, camera.rs:19-20), a general affine inverse."""
+    for axis in "xyz":
+        for deg in (0.0, 20.0, 35.0, -20.0, 90.0, 120.0, 45.0, 180.0, 270.0):
+            np.testing.assert_allclose(_m4(rt, "from_angle_" + axis, [deg]), _rot64(axis, deg), atol=1e-6)
+    # scene.rs:35-38: translate * rotate_x(90) * translate.invert()
+    t = _m4(rt, "from_translation", [1.0, 0.5, -2.0])
+    o2w = _m4(rt, "mul", _m4(rt, "mul", t, _m4(rt, "from_angle_x", [90.0])), _m4(rt, "invert", t))
+    t64 = np.eye(4)
+    t64[:3, 3] = (1.0, 0.5, -2.0)
+    np.testing.assert_allclose(o2w, t64 @ _rot64("x", 90) @ np.linalg.inv(t64), atol=1e-6)
+    # scene.rs:194-199: translation(0) * scale(1) * (Ry(20) * Rz(35) * Rx(-20))
+    rot = _m4(rt, "mul", _m4(rt, "mul", _m4(rt, "from_angle_y", [20.0]), _m4(rt, "from_angle_z", [35.0])), _m4(rt, "from_angle_x", [-20.0]))
+    suz = _m4(rt, "mul", _m4(rt, "mul", _m4(rt, "from_translation", [0.0, 0.0, 0.0]), _m4(rt, "from_nonuniform_scale", [1.0, 1.0, 1.0])), rot)
+    suz64 = _rot64("y", 20) @ _rot64("z", 35) @ _rot64("x", -20)
+    np.testing.assert_allclose(suz, suz64, atol=1e-6)
+    np.testing.assert_allclose(_m4(rt, "invert", suz), np.linalg.inv(suz64), atol=1e-6)
+    # default_camera: look_at((0,1.5,5), origin, +y) and camera_to_world = its inverse
+    la = _m4(rt, "look_at", [0.0, 1.5, 5.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0])
+    la64 = _look_at64((0, 1.5, 5), (0, 0, 0), (0, 1, 0))
+    np.testing.assert_allclose(la, la64, atol=1e-6)
+    np.testing.assert_allclose(_m4(rt, "invert", la), np.linalg.inv(la64), atol=2e-6)
+    # ... which is the matrix the scene descriptions carry
+    s = rt.HostScene("basic", 16)
+    c2w = np.array(list(s.desc.contents.camera_to_world), np.float32).reshape(4, 4).T
+    np.testing.assert_array_equal(c2w, _m4(rt, "invert", la))
+    # a general affine matrix (rotation, non-uniform scale incl. a negative one, shear through the product, translation)
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        a = np.eye(4)
+        a[:3, :3] = rng.uniform(-2, 2, (3, 3)) + 2.5 * np.diag(rng.choice([-1.0, 1.0], 3))
+        a[:3, 3] = rng.uniform(-5, 5, 3)
+        a32 = a.astype(np.float32)
+        inv = _m4(rt, "invert", a32)
+        np.testing.assert_allclose(inv.astype(np.float64) @ a32.astype(np.float64), np.eye(4), atol=2e-5)
+        p = rng.uniform(-3, 3, 3).astype(np.float32)
+        np.testing.assert_allclose(_m4(rt, "transform_point", a32, p), (a32.astype(np.float64) @ np.append(p, 1.0))[:3], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_m4(rt, "transform_vector", a32, p), a32[:3, :3].astype(np.float64) @ p, rtol=1e-5, atol=1e-5)
+    with pytest.raises(rt.RtxError) as e:
+        _m4(rt, "invert", np.zeros((4, 4), np.float32))
+    assert e.value.status == rt.RTX_ERR_DEGENERATE
