@@ -31,6 +31,12 @@ def orc():
 
 @pytest.fixture(scope="session")
 def gpu(rt):
+    # The GPU tests are about the library on the runtime it is linked against.  A process that imported torch first has
+    # torch's bundled librccl / libamdhip64 underneath librtx_hip.so instead: say so rather than test something else.
+    info = rt.comm_info()
+    if info.count("/opt/rocm") != 2:
+        pytest.fail("librtx_hip.so is not running on /opt/rocm's RCCL + HIP runtime (" + info + "): run the GPU tests in a "
+                    "process of their own (pytest -m gpu), without torch imported")
     ctx = rt.Context(0)
     yield ctx
     ctx.close()

@@ -9,13 +9,16 @@ import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.multiprocessing as mp
+
+# torch is imported inside the tests, never at module level: `pytest -m gpu` collects this file too, and a process that
+# has imported torch binds torch's bundled librccl / HIP runtime under librtx_hip.so instead of /opt/rocm's
+# (tests/test_gpu_comm.py::test_comm_info_names_the_linked_runtime checks which one a GPU run got).
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, width, tile, out_dir):
+    import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -38,6 +41,7 @@ def _worker(rank, world, port, width, tile, out_dir):
 
 @pytest.mark.parametrize("width,tile", [(64, 32), (100, 32), (40, 16)])
 def test_two_rank_gather_matches_full_image(tmp_path, width, tile):
+    import torch.multiprocessing as mp
     port = 29500 + (os.getpid() + width) % 2000
     mp.spawn(_worker, args=(2, port, width, tile, str(tmp_path)), nprocs=2, join=True)
     full = np.load(tmp_path / "full.npy")
@@ -54,6 +58,7 @@ def test_partition_counts():
 
 
 def test_assemble_single_rank_roundtrip():
+    import torch
     tl = importlib.import_module("rust-raytracer_amd.tiles")
     rng = np.random.default_rng(0)
     img = torch.from_numpy(rng.integers(0, 255, (70, 70, 3), dtype=np.uint8))
@@ -78,8 +83,15 @@ def _rdzv_worker(rank, world, path, out_dir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_rendezvous_star(tmp_path, world):
     """The TCP star that carries bench.py's RCCL id, barriers and reductions at N > 1 (world size 2 and 3, CPU)."""
+    import multiprocessing
     path = str(tmp_path / "rdzv")
-    mp.spawn(_rdzv_worker, args=(world, path, str(tmp_path)), nprocs=world, join=True)
+    ctx = multiprocessing.get_context("spawn")
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, path, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
     want = repr(("id-" + "ab" * 64, [[r, 1.5 * r] for r in range(world)], [1000 + r for r in range(world)], list(range(world))))
     for r in range(world):
         assert (tmp_path / f"r{r}.txt").read_text() == want
