@@ -351,20 +351,31 @@ def main():
         return {"rays_per_step": int(rays), "algorithmic_bytes_per_step": int(nbytes), "bytes_per_ray": round(nbytes / max(rays, 1), 1),
                 "nodes_per_ray": round(nodes / max(rays, 1), 3), "prims_per_ray": round(prims / max(rays, 1), 3)}
 
-    if valu:  # lane-instructions: VALU instructions x the lanes that executed them
+    # The memory side (fabric reads behind L2 against the level the scene lives in) and, when the PMC summary is valid, the
+    # VALU side: lane-instructions = VALU instructions x the lanes that executed them, against the chip's f32 vector rate
+    # (MI355X_MICROARCH.md: 157.3 TFLOP/s f32 = 78.6 T lane-FMA/s, a SIMD retiring a wave64 instruction every 2 cycles).
+    memory = {"achieved": round(achieved, 2) if achieved is not None else None, "peak": peak, "unit": "GB/s",
+              "frac": round(achieved / peak, 5) if achieved is not None else None,
+              "peak_is": ("random 128-byte gathers from L2 + Infinity Cache (scene %.0f MB <= 256 MB)" % (info.device_bytes / 2**20)) if in_mall
+                         else "HBM3E (scene %.0f MB > Infinity Cache)" % (info.device_bytes / 2**20),
+              "frac_basis": basis}
+    VALU_PEAK_T = 78.6
+    if valu:
         li = valu["insts_per_launch"] * 64.0 * valu["active_lane_fraction"]
+        rate = li / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         valu = dict(valu, lane_instr_per_ray=round(li / max(t_rays / max(launches_per_step, 1), 1), 1),
-                    lane_instr_rate_T_per_s=round(li / (avg_launch_ms * 1e-3) / 1e12, 2) if avg_launch_ms > 0 else None,
-                    lane_instr_peak_T_per_s=round(256 * 4 * 64 / 4 * 2.4e9 / 1e12, 1),   # 1,024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
-                    note="issue_cycles_over_kernel_cycles counts 4 cycles per wave64 VALU instruction (one wave's issue cost); measured in "
-                         "round 3: 14 % fewer VALU instructions bought 5 % of the kernel's time, the waves wait 45 % of their life for loads "
-                         "(SQ_WAIT_ANY / SQ_WAVE_CYCLES): issue AND load latency at 5 waves per SIMD")
+                    lane_instr_rate_T_per_s=round(rate, 2), lane_instr_peak_T_per_s=VALU_PEAK_T,
+                    note="issue_cycles_over_kernel_cycles prices a wave64 VALU instruction at the 4 cycles it holds its wave's issue slot (a SIMD "
+                         "interleaves two such streams at most): 0.9+ means the issue slots are taken, at active_lane_fraction of the lanes.  "
+                         "Measured in round 3: 14 % fewer VALU instructions bought 5 % of the kernel's time and the waves wait 45 % of "
+                         "their life for loads (SQ_WAIT_ANY / SQ_WAVE_CYCLES): instruction issue AND load latency at 5 waves per SIMD bind together")
+    if bound == "valu":
+        head = {"achieved": valu["lane_instr_rate_T_per_s"], "peak": VALU_PEAK_T, "unit": "T lane-instr/s",
+                "frac": round(valu["lane_instr_rate_T_per_s"] / VALU_PEAK_T, 5)}
+    else:
+        head = {k: memory[k] for k in ("achieved", "peak", "unit", "frac")}
     roofline = {"bound": bound, "kernel": "path_kernel (closest-hit + shadow queries of all bounce levels, one persistent launch per batch)",
-                "achieved": round(achieved, 2) if achieved is not None else None, "peak": peak, "unit": "GB/s",
-                "frac": round(achieved / peak, 5) if achieved is not None else None, "traffic": traffic,
-                "peak_is": ("random 128-byte gathers from L2 + Infinity Cache (scene %.0f MB <= 256 MB)" % (info.device_bytes / 2**20)) if in_mall
-                           else "HBM3E (scene %.0f MB > Infinity Cache)" % (info.device_bytes / 2**20),
-                "frac_basis": basis, "pmc": pmc_note,
+                **head, "traffic": traffic, "memory": memory, "pmc": pmc_note,
                 "record_delivery_GBps": round(delivery, 2),   # algorithmic bytes / time: records come from LDS, L1, L2 too
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
                 "launches_per_step": launches_per_step, "slots": n_slots, "resolve_ms_per_step": round(r_ms, 4),
