@@ -50,6 +50,8 @@ enum {
     CTR_SVISIT_PRIMS_LO,
     CTR_SVISIT_PRIMS_HI,
     CTR_MAX_STEPS,          // most records visited by a single ray (COUNT)
+    CTR_PRE_DEEP,           // primaries-first launches: primary hits whose material spawns bounce rays,
+    CTR_PRE_SHALLOW,        // ... and the other primary hits (written by pre_scan_kernel)
     CTR_UTIL = 20,          // [22] 64-bit lane-utilisation census (RTX_UTIL_STATS builds)
     CTR_WORDS = 64
 };
@@ -60,7 +62,9 @@ enum {
 enum {
     QPARTS = 16,
     QHEAD_STRIDE = 32,  // words
-    WORK_WORDS = QPARTS * QHEAD_STRIDE,
+    WORK_HALF = QPARTS * QHEAD_STRIDE,
+    WORK_WORDS = 2 * WORK_HALF,  // two sets of heads: a primaries-first launch runs two persistent kernels per batch
+    PRE_SEG = 4096,     // primaries per block of the classification passes between them
     POOL_RUN = 128,     // bounce-child path nodes a wave reserves with one atomic
     SHADE_LIST = 192    // hits a wave can have waiting for its shading pass (behind its work stack)
 };
@@ -84,6 +88,8 @@ struct Frame {
     uint32_t *spill;    // traversal-stack overflow, [spill entries][threads] of (ref, t)
     uint32_t node_cap, wstack_cap;
     uint32_t stripe;    // entries of the queue of primaries that make one stripe (WaveQueue): 64 pixel slots x the batch's samples
+    uint32_t *preq;     // primaries-first launches: the primary hits in queue order, those with bounce materials from the front, the others from the back (n0 entries); else nullptr
+    uint32_t *pre_blocks;  // ... and the two counts / offsets of every PRE_SEG primaries
 };
 
 struct BatchInfo {
@@ -102,6 +108,7 @@ struct LaunchCfg {
     bool count_visits;
     bool reference_traversal;
     bool leaf_bank = false;  // the path kernel variant that sets leaves aside during node steps (kernels.hip, wave_step)
+    bool primaries_first = false;  // trace the primaries alone, then the rest from their hits, bounce materials first (launch_path)
 };
 
 void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, const LaunchCfg &lc);
@@ -112,7 +119,12 @@ void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const L
 // closest hit, the shadow query of every light (light.rs:81-122), the bounce rays of
 // material.rs:185-203 -- each of them a path node whose record the resolve pass reads.
 // shade == false: closest hits of the primaries only (rtx_trace_primary / rtx_trace_rays).
-void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc);
+// lc.primaries_first (shade, production traversal, no counters, fr.preq set, n0 primaries in the frame): the same
+// in two persistent launches -- the primaries' closest hits first; then the hits are listed, those whose
+// material spawns bounce rays first (three small launches: count, scan, scatter; stable, so the queue keeps its
+// order within a class), and the second launch starts from that list: the long dependent chains of a frame begin
+// when the launch begins, not when their primary's turn comes.
+void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc, uint32_t n0 = 0);
 // Resolves the colours of the path nodes of one bounce level (material.rs:118-206), deepest level
 // first: a node's bounce children have their colours by then.
 void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc);

@@ -1004,6 +1004,9 @@ __device__ __forceinline__ void object_uv(const PrimView &v, const Xform *xforms
 #ifndef RTX_SHADE_MIN
 #define RTX_SHADE_MIN 32
 #endif
+#ifndef RTX_CHAIN_PRIO
+#define RTX_CHAIN_PRIO 1
+#endif
 constexpr uint32_t WK_LIGHT = 31u, WK_DIR = 1u << 5, WK_SHADOW = 1u << 6, WK_BUSY = 1u << 7, WK_LEVEL_SHIFT = 8;
 
 // light.rs:113-116: is `point` outside the cone?  The reference compares atan2(|a x b|, a . b)
@@ -1033,7 +1036,7 @@ __device__ __forceinline__ void ray_hist(uint32_t *ctr, uint32_t cls, uint32_t r
     atomicAdd(ctr + CTR_WORDS + 128u + cls * 16u + b, records);
 }
 #endif
-template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK>
+template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK, bool PRE>
 __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
@@ -1079,9 +1082,14 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     const uint32_t wt_begin = (uint32_t)wall_clock64();
     uint32_t wt_dry = 0;
 #endif
+    // PRE: the queue is the list of primary hits (launch_path, primaries first), nd of them with bounce materials
+    const uint32_t nd = PRE ? fr.counters[CTR_PRE_DEEP] : 0u;
     WaveQueue wq;
-    wq.init(fr.work, n0, fr.stripe, nthreads / 64u, gtid / 64u);
+    wq.init(PRE ? fr.work + WORK_HALF : fr.work, PRE ? nd + fr.counters[CTR_PRE_SHALLOW] : n0, fr.stripe, nthreads / 64u, gtid / 64u);
     uint32_t refill_min = (uint32_t)RTX_REFILL_MIN, steps_run = 0;  // wave-uniform
+#if RTX_CHAIN_PRIO
+    bool prio_up = false;
+#endif
     float end_rate = -1.0f;                                         // rays ending per step, running mean
 #ifdef RTX_UTIL_STATS
     const unsigned long long t_begin = wall_clock64();
@@ -1329,7 +1337,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                         const unsigned long long um = __ballot(unserved);
                         if (um == 0ull) break;
                         if (wq.take(um, unserved, i)) {
-                            node = i;
+                            node = PRE ? fr.preq[i < nd ? i : n0 - 1u - (i - nd)] : i;
                             tag = WK_BUSY;  // closest-hit query, level 0
                             got = true;
                             unserved = false;
@@ -1361,7 +1369,14 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                         dist = magnitude(ro - p);
                     }
                 }
-                if (!(tag & WK_SHADOW) && __float_as_uint(d4.w) == INVALID_PRIM) {  // pixel slot outside the image (padded tile)
+                if (PRE && tag == WK_BUSY) {
+                    // a primary hit of the first launch: nothing to trace, it joins the hits that wait for shading
+                    s.cur = s.bank = TRAV_DONE;
+                    s.any = true;
+                    s.t = o4.w;
+                    s.prim = __float_as_uint(d4.w);
+                    if (COUNT) s.nodes = s.prims = 0;
+                } else if (!(tag & WK_SHADOW) && __float_as_uint(d4.w) == INVALID_PRIM) {  // pixel slot outside the image (padded tile)
                     if (SHADE) fr.link[node] = make_uint2(0u, NO_PRIM);
                     tag = 0;
                 } else {
@@ -1372,6 +1387,21 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             }
             RTX_SECTION(3)
         }
+#if RTX_CHAIN_PRIO
+        // A frame's launch is as long as its longest sample: closest hit after closest hit down the bounce levels,
+        // every step of every ray a dependent load.  A wave that carries such a link -- a closest-hit query of a
+        // bounce level -- issues ahead of the waves it shares its SIMD with.  (Measured, round 3: rank 0's 1/8 share
+        // of the headline frame 2.44 -> 2.28 ms, configs 1 and 2 -2 %, the whole frame +-0; priority 1 and 3 alike.
+        // Passing as soon as such a query ends instead of waiting for the pass threshold: +-0 / +1.5 %.)
+        if constexpr (SHADE) {
+            const bool chain = __ballot((tag & (WK_BUSY | WK_SHADOW)) == WK_BUSY && (tag >> WK_LEVEL_SHIFT) != 0u) != 0ull;
+            if (chain != prio_up) {
+                if (chain) __builtin_amdgcn_s_setprio(RTX_CHAIN_PRIO);
+                else __builtin_amdgcn_s_setprio(0);
+                prio_up = chain;
+            }
+        }
+#endif
     }
 #ifdef RTX_WAVE_TIMES
     if (SHADE && lane == 0) {
@@ -1424,15 +1454,115 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     }
 }
 
-template <bool COUNT, bool REF, bool SHADE, bool BANK = false>
+template <bool COUNT, bool REF, bool SHADE, bool BANK = false, bool PRE = false>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, REF, false, SHADE, BANK>(sc, fr, max_levels);
+    path_body<COUNT, REF, false, SHADE, BANK, PRE>(sc, fr, max_levels);
 }
 // The production traversal for scenes whose hits can lie outside their objects' boxes
 // (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
-template <bool COUNT, bool SHADE>
+template <bool COUNT, bool SHADE, bool PRE = false>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_ovh_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, false, true, SHADE, false>(sc, fr, max_levels);
+    path_body<COUNT, false, true, SHADE, false, PRE>(sc, fr, max_levels);
+}
+
+// ---------------------------------------------------------------- primaries first: the list of primary hits
+// Between the two persistent launches of a primaries-first batch (launch_path).  A primary that hit nothing (or
+// whose pixel slot lies outside the image) gets the record the path kernel would have written; a hit is classed
+// by its material -- 1: spawns bounce rays, 2: does not -- in link.x, which nothing reads before the second
+// launch's shading pass overwrites it.  Blocks of PRE_SEG primaries count, one block scans, the same blocks scatter:
+// the list keeps the queue's order within each class.
+__global__ void __launch_bounds__(BLOCK) pre_count_kernel(DeviceScene sc, Frame fr, uint32_t n0) {
+    __shared__ uint32_t cnt[2];
+    if (threadIdx.x < 2u) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t seg = blockIdx.x * (uint32_t)PRE_SEG;
+    uint32_t c1 = 0, c2 = 0;
+    for (uint32_t k = 0; k < (uint32_t)PRE_SEG / BLOCK; k++) {
+        const uint32_t i = seg + k * BLOCK + threadIdx.x;
+        if (i >= n0) break;
+        const uint32_t prim = __float_as_uint(fr.ray_d[i].w);
+        uint32_t cls = 0;
+        if (prim < INVALID_PRIM) cls = sc.mats[sc.prims[prim].meta >> 16].n_bounce != 0u ? 1u : 2u;
+        fr.link[i] = make_uint2(cls, NO_PRIM);   // (cls 0: the final record of a miss, world.rs:127-130)
+        c1 += cls == 1u;
+        c2 += cls == 2u;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        c1 += __shfl_down(c1, d, 64);
+        c2 += __shfl_down(c2, d, 64);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&cnt[0], c1);
+        atomicAdd(&cnt[1], c2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) fr.pre_blocks[2u * blockIdx.x + threadIdx.x] = cnt[threadIdx.x];
+}
+__global__ void __launch_bounds__(1024) pre_scan_kernel(Frame fr, uint32_t nblocks) {
+    __shared__ uint32_t part[2][1024];
+    const uint32_t t = threadIdx.x, per = (nblocks + 1023u) / 1024u;
+    const uint32_t b0 = t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        s1 += fr.pre_blocks[2u * b];
+        s2 += fr.pre_blocks[2u * b + 1u];
+    }
+    part[0][t] = s1;
+    part[1][t] = s2;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // inclusive scan of the 1024 partial sums
+        const uint32_t a1 = t >= d ? part[0][t - d] : 0u, a2 = t >= d ? part[1][t - d] : 0u;
+        __syncthreads();
+        part[0][t] += a1;
+        part[1][t] += a2;
+        __syncthreads();
+    }
+    uint32_t o1 = part[0][t] - s1, o2 = part[1][t] - s2;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t c1 = fr.pre_blocks[2u * b], c2 = fr.pre_blocks[2u * b + 1u];
+        fr.pre_blocks[2u * b] = o1;
+        fr.pre_blocks[2u * b + 1u] = o2;
+        o1 += c1;
+        o2 += c2;
+    }
+    if (t == 1023u) {
+        fr.counters[CTR_PRE_DEEP] = part[0][t];
+        fr.counters[CTR_PRE_SHALLOW] = part[1][t];
+    }
+}
+__global__ void __launch_bounds__(BLOCK) pre_scatter_kernel(Frame fr, uint32_t n0) {
+    __shared__ uint32_t wcnt[2][BLOCK / 64];
+    __shared__ uint32_t base[2];
+    const uint32_t seg = blockIdx.x * (uint32_t)PRE_SEG, w = threadIdx.x / 64u;
+    const unsigned long long lt = (1ull << lane_id()) - 1ull;
+    if (threadIdx.x < 2u) base[threadIdx.x] = fr.pre_blocks[2u * blockIdx.x + threadIdx.x];
+    for (uint32_t k = 0; k < (uint32_t)PRE_SEG / BLOCK; k++) {
+        const uint32_t i = seg + k * BLOCK + threadIdx.x;
+        const uint32_t cls = i < n0 ? fr.link[i].x : 0u;
+        const unsigned long long m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+        if (lane_id() == 0) {
+            wcnt[0][w] = (uint32_t)__popcll(m1);
+            wcnt[1][w] = (uint32_t)__popcll(m2);
+        }
+        __syncthreads();
+        uint32_t o1 = base[0], o2 = base[1], t1 = 0, t2 = 0;
+        for (uint32_t v = 0; v < BLOCK / 64u; v++) {
+            if (v < w) {
+                o1 += wcnt[0][v];
+                o2 += wcnt[1][v];
+            }
+            t1 += wcnt[0][v];
+            t2 += wcnt[1][v];
+        }
+        if (cls == 1u) fr.preq[o1 + (uint32_t)__popcll(m1 & lt)] = i;
+        if (cls == 2u) fr.preq[n0 - 1u - (o2 + (uint32_t)__popcll(m2 & lt))] = i;
+        const uint32_t nb1 = base[0] + t1, nb2 = base[1] + t2;
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            base[0] = nb1;
+            base[1] = nb2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- resolve
@@ -1700,9 +1830,21 @@ void launch_raygen(const DeviceScene &sc, const Frame &fr, const BatchInfo &bi, 
 void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const LaunchCfg &lc) {
     hipLaunchKernelGGL(load_rays_kernel, dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, lc.stream, fr, org_dir, n);
 }
-void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc) {
+void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc, uint32_t n0) {
     dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
 #define RTX_LAUNCH_PATH(K) hipLaunchKernelGGL(K, g, b, 0, lc.stream, sc, fr, max_levels)
+    if (shade && lc.primaries_first && !lc.reference_traversal && !lc.count_visits && !lc.leaf_bank && fr.preq && fr.pre_blocks && n0 != 0u) {
+        const bool ovh = sc.overhang != 0.0f;
+        if (ovh) RTX_LAUNCH_PATH((path_ovh_kernel<false, false>));
+        else RTX_LAUNCH_PATH((path_kernel<false, false, false>));
+        const uint32_t nblocks = (n0 + (uint32_t)PRE_SEG - 1u) / (uint32_t)PRE_SEG;
+        hipLaunchKernelGGL(pre_count_kernel, dim3(nblocks), dim3(BLOCK), 0, lc.stream, sc, fr, n0);
+        hipLaunchKernelGGL(pre_scan_kernel, dim3(1), dim3(1024), 0, lc.stream, fr, nblocks);
+        hipLaunchKernelGGL(pre_scatter_kernel, dim3(nblocks), dim3(BLOCK), 0, lc.stream, fr, n0);
+        if (ovh) RTX_LAUNCH_PATH((path_ovh_kernel<false, true, true>));
+        else RTX_LAUNCH_PATH((path_kernel<false, false, true, false, true>));
+        return;
+    }
     if (!shade) {  // closest hits of the primaries only (no visit counters on this path)
         if (lc.reference_traversal) RTX_LAUNCH_PATH((path_kernel<false, true, false>));
         else if (sc.overhang != 0.0f) RTX_LAUNCH_PATH((path_ovh_kernel<false, false>));

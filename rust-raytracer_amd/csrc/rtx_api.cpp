@@ -38,6 +38,8 @@ struct Pipe {
     Frame fr{};
     std::vector<void *> allocs;
     uint64_t n0_cap = 0, node_cap = 0;
+    uint64_t preq_cap = 0;            // primaries the list of a primaries-first launch holds (ensure_preq)
+    uint32_t *preq = nullptr, *pre_blocks = nullptr;   // ... (kept here: ensure_frame starts its Frame afresh)
     uint32_t spill_entries = 0, wstack_cap = 0;
     hipStream_t main = nullptr;
     float4 *sum = nullptr;            // per-pixel sums of a render cut into several batches
@@ -90,6 +92,8 @@ struct rtx_ctx {
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
     uint32_t *h_noalloc_flag = nullptr;  // pinned word: CTR_OVERFLOW of the last rtx_render_device_noalloc (allocated by rtx_init)
     bool noalloc_pending = false;     // ... which nobody has looked at yet (rtx_synchronize / rtx_slot_synchronize(0) do)
+    int primaries_first = -1;         // RTX_PRIMARIES_FIRST: 0 never, 1 always, -1 = by batch size
+    uint32_t primaries_first_below = 0;  // RTX_PRIMARIES_FIRST_BELOW: ... batches of fewer primaries per wave than this
     uint32_t stripe_blocks = 1;       // RTX_STRIPE_BLOCKS: 8x8 pixel blocks (with all their samples) per stripe of the queue of primaries
     long test_pool_nodes = -1;        // RTX_TEST_POOL_NODES: tests shrink the pool of bounce children to force the overflow report
 };
@@ -265,6 +269,24 @@ int ensure_frame(rtx_ctx *c, Pipe &pp, uint64_t n0, uint32_t levels) {
     return RTX_OK;
 }
 
+// The list of primary hits of a primaries-first launch (launch_path): 4 bytes per primary plus the block counts,
+// outside the node budget, grown on demand.
+int ensure_preq(rtx_ctx *c, Pipe &pp, uint64_t n0) {
+    if (!(pp.preq && n0 <= pp.preq_cap)) {
+        HIP_TRY(c, hipStreamSynchronize(pp.main));
+        if (pp.preq) (void)hipFree(pp.preq);
+        if (pp.pre_blocks) (void)hipFree(pp.pre_blocks);
+        pp.preq = pp.pre_blocks = nullptr;
+        pp.preq_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&pp.preq, std::max<size_t>(n0 * sizeof(uint32_t), 256)));
+        HIP_TRY(c, hipMalloc((void **)&pp.pre_blocks, std::max<size_t>(((n0 + PRE_SEG - 1) / PRE_SEG) * 2 * sizeof(uint32_t), 256)));
+        pp.preq_cap = n0;
+    }
+    pp.fr.preq = pp.preq;
+    pp.fr.pre_blocks = pp.pre_blocks;
+    return RTX_OK;
+}
+
 int reset_counters(rtx_ctx *c, Pipe &pp) {
     static const bool util_print = std::getenv("RTX_UTIL_PRINT") != nullptr;  // diagnostic builds (-DRTX_UTIL_STATS)
     HIP_TRY(c, hipMemsetAsync(pp.fr.work, 0, (WORK_WORDS + CTR_WORDS) * sizeof(uint32_t), pp.main));
@@ -325,10 +347,22 @@ struct Batch {
 // path kernel (every ray of every bounce level), then the colours bottom-up, one streaming pass
 // per level.  Records 3 timing events starting at events[ev0] when timing is on: path begin, path
 // end, resolves end.
-int run_path(rtx_ctx *c, Pipe &lane, std::vector<hipEvent_t> &events, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0) {
+int run_path(rtx_ctx *c, Pipe &lane, std::vector<hipEvent_t> &events, LaunchCfg lc, uint32_t levels, bool timing, size_t ev0,
+             uint64_t n0 = 0) {
     lc.stream = lane.main;
+    // Primaries first (launch_path): RTX_PRIMARIES_FIRST=0/1 forces it off / on; by default batches of fewer than
+    // primaries_first_below primaries per wave of the grid, whose launch is mostly its end phase
+    lc.primaries_first = false;
+    if (n0 != 0 && levels != 0 && !lc.count_visits && !lc.reference_traversal && !lc.leaf_bank && c->primaries_first != 0) {
+        const uint64_t waves = (uint64_t)std::max(1, lc.persistent_blocks) * 4;
+        if (c->primaries_first > 0 || n0 < (uint64_t)c->primaries_first_below * waves) {
+            const int rc = ensure_preq(c, lane, n0);
+            if (rc != RTX_OK) return rc;
+            lc.primaries_first = true;
+        }
+    }
     if (timing) (void)hipEventRecord(events[ev0], lane.main);
-    if (levels) launch_path(c->ds, lane.fr, levels, true, lc);   // trace_ray(.., 0) is the background (world.rs:116-117)
+    if (levels) launch_path(c->ds, lane.fr, levels, true, lc, (uint32_t)n0);   // trace_ray(.., 0) is the background (world.rs:116-117)
     if (timing) (void)hipEventRecord(events[ev0 + 1], lane.main);
     // a level deeper than 0 exists only if some material spawns bounce rays
     for (int k = (c->max_bounce ? (int)levels - 1 : 0); k >= 1; k--) launch_resolve(c->ds, lane.fr, (uint32_t)k, lc);
@@ -580,7 +614,7 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
                                                                              std::max<uint64_t>(256, (uint64_t)b.npix * b.ns / 1024));
             lane.fr.stripe = 64u * c->stripe_blocks * std::min(b.ns, 4096u);
             launch_raygen(c->ds, lane.fr, info, lc);
-            rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi);
+            rc = run_path(c, lane, pp.events, lc, levels, timing, ev_per_batch * bi, (uint64_t)b.npix * b.ns);
             if (rc != RTX_OK) return rc;
             // sums are folded in sample order (world.rs:54-61): the batches follow each other on the stream,
             // or, with two lanes, batch k's accumulate waits for batch k-1's on the other stream
@@ -680,6 +714,8 @@ int rtx_init(int device, rtx_ctx **out) {
         return RTX_ERR_HIP;
     }
     *c->h_noalloc_flag = 0;
+    if (const char *pf = std::getenv("RTX_PRIMARIES_FIRST")) c->primaries_first = std::atoi(pf) != 0;
+    if (const char *pb = std::getenv("RTX_PRIMARIES_FIRST_BELOW")) c->primaries_first_below = (uint32_t)std::max(0, std::atoi(pb));
     if (const char *sb = std::getenv("RTX_STRIPE_BLOCKS")) c->stripe_blocks = (uint32_t)std::min(1024, std::max(1, std::atoi(sb)));
     if (const char *tp = std::getenv("RTX_TEST_POOL_NODES")) c->test_pool_nodes = std::max(0L, std::atol(tp));
     if (const char *lb = std::getenv("RTX_LEAF_BANK")) c->leaf_bank = std::atoi(lb) != 0;
@@ -705,11 +741,15 @@ void rtx_destroy(rtx_ctx *c) {
         if (pp.lane2) {
             if (pp.lane2->main) (void)hipStreamSynchronize(pp.lane2->main);
             free_all(pp.lane2->allocs);
+            if (pp.lane2->preq) (void)hipFree(pp.lane2->preq);
+            if (pp.lane2->pre_blocks) (void)hipFree(pp.lane2->pre_blocks);
             if (pp.lane2->main) (void)hipStreamDestroy(pp.lane2->main);
         }
         for (hipEvent_t e : {pp.ev_begin, pp.ev_end, pp.ev_acc[0], pp.ev_acc[1]})
             if (e) (void)hipEventDestroy(e);
         free_all(pp.allocs);
+        if (pp.preq) (void)hipFree(pp.preq);
+        if (pp.pre_blocks) (void)hipFree(pp.pre_blocks);
         if (pp.sum) (void)hipFree(pp.sum);
         if (pp.h_counters) (void)hipHostFree(pp.h_counters);
         for (auto e : pp.events) (void)hipEventDestroy(e);

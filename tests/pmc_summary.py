@@ -38,7 +38,7 @@ if len(sys.argv) > 4:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     rt = importlib.import_module("rust-raytracer_amd")
     out_path, wkey, note = sys.argv[2], sys.argv[3], sys.argv[4]
-    kname = [k for k in tot if k.startswith("path_kernel<false, false, true") or k.startswith("path_ovh_kernel<false, true>")]
+    kname = [k for k in tot if k.startswith("path_kernel<false, false, true") or k.startswith("path_ovh_kernel<false, true")]
     if kname:
         k = kname[0]
         c = tot[k]

@@ -494,6 +494,34 @@ def test_leaf_banking_variant_is_exact(rt, orc, monkeypatch, name, width, param,
     assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
 
 
+@pytest.mark.parametrize("name,width,param,spp,part", [("scan_glass", 256, 30000, 4, None), ("basic_suzanne", 200, 0, 3, (32, 1, 3)),
+                                                       ("random_spheres", 128, 300, 1, None), ("basic", 768, 0, 2, None)])
+def test_primaries_first_launch_is_exact(rt, monkeypatch, name, width, param, spp, part):
+    """RTX_PRIMARIES_FIRST=1: the primaries' closest hits in a launch of their own, the hits listed with the bounce
+    materials first (count / scan / scatter), the rest of every path tree from that list in a second persistent
+    launch (kernels.h, launch_path).  Another order of the same work: tile bytes and ray counts must not differ in
+    a bit from the single launch's -- padded tiles (width 200), a partition, two batches and a scene whose hits lie
+    outside their boxes (path_ovh_kernel) included."""
+    s = rt.HostScene(name, width, param)
+    frames, stats = [], []
+    for pf in ("0", "1"):
+        monkeypatch.setenv("RTX_PRIMARIES_FIRST", pf)
+        if name == "basic": monkeypatch.setenv("RTX_MIN_BATCHES", "2")
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            buf = rt.DeviceBuffer(c.partition_pixels(part) * 3)
+            st = c.render_device(buf.ptr, spp, 4, seed=5, part=part)
+            frames.append(buf.to_host())
+            stats.append(st)
+        finally:
+            c.close()
+    assert frames[0].any()
+    assert np.array_equal(frames[0], frames[1]), f"{(frames[0] != frames[1]).sum()} bytes differ"
+    assert (stats[0].primary_rays, stats[0].bounce_rays, stats[0].shadow_rays) == (stats[1].primary_rays, stats[1].bounce_rays, stats[1].shadow_rays)
+    if name == "basic": assert stats[1].batches >= 2
+
+
 def test_errors(rt, gpu):
     c = rt.Context(0)
     with pytest.raises(rt.RtxError) as e:
