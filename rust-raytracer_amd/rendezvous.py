@@ -62,22 +62,18 @@ class Rendezvous:
             srv.close()
             self.peers = [peers[r] for r in range(1, world)]
         else:
-            port = None
-            while port is None:
+            addr = "127.0.0.1" if host in ("127.0.0.1", "localhost") else host
+            while self.sock is None:
+                # the file is read again after every failed attempt: one left behind by an earlier job of the same
+                # name (a launcher pid used twice) names a port nobody listens on until rank 0 has replaced it
                 try:
                     with open(path) as f:
                         port = json.load(f)["port"]
+                    self.sock = socket.create_connection((addr, port), timeout=timeout)
                 except (OSError, ValueError, KeyError):
+                    self.sock = None
                     if time.time() > deadline:
-                        raise TimeoutError(f"rendezvous file {path} did not appear")
-                    time.sleep(0.02)
-            while True:
-                try:
-                    self.sock = socket.create_connection(("127.0.0.1" if host in ("127.0.0.1", "localhost") else host, port), timeout=timeout)
-                    break
-                except OSError:
-                    if time.time() > deadline:
-                        raise
+                        raise TimeoutError(f"no rendezvous with rank 0 through {path}")
                     time.sleep(0.02)
             self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             _send(self.sock, {"rank": rank})

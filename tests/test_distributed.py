@@ -80,15 +80,26 @@ def _rdzv_worker(rank, world, path, out_dir):
     rv.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_rendezvous_star(tmp_path, world):
-    """The TCP star that carries bench.py's RCCL id, barriers and reductions at N > 1 (world size 2 and 3, CPU)."""
-    import multiprocessing
+@pytest.mark.parametrize("world,stale", [(2, False), (3, False), (3, True)])
+def test_rendezvous_star(tmp_path, world, stale):
+    """The TCP star that carries bench.py's RCCL id, barriers and reductions at N > 1 (world size 2 and 3, CPU).
+    stale: a file of the same name left behind by an earlier job names a port nobody listens on; the other ranks are
+    started first, find it, and must still meet rank 0 once it has replaced the file."""
+    import json, multiprocessing, socket, time
     path = str(tmp_path / "rdzv")
+    if stale:
+        dead = socket.socket()
+        dead.bind(("127.0.0.1", 0))
+        with open(path, "w") as f:
+            json.dump({"port": dead.getsockname()[1], "pid": 1}, f)
+        dead.close()
     ctx = multiprocessing.get_context("spawn")
     procs = [ctx.Process(target=_rdzv_worker, args=(r, world, path, str(tmp_path))) for r in range(world)]
-    for p in procs:
+    for p in (procs[1:] if stale else procs):
         p.start()
+    if stale:
+        time.sleep(1.0)
+        procs[0].start()
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
