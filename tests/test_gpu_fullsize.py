@@ -83,6 +83,23 @@ def test_config3_headline_16spp_batching(rt, gpu, monkeypatch):
         c2.close()
 
 
+def test_config3_headline_primaries_first(rt, gpu, monkeypatch):
+    """The headline frame as a primaries-first launch (RTX_PRIMARIES_FIRST=1: 16.8 M primaries, 4,096 blocks of the
+    classification passes, four of them per thread of the scan): the same bytes and ray counts as the single launch."""
+    s = rt.HostScene("scan", 1024, 0)
+    gpu.upload(s)
+    ref, st = gpu.render(spp=16, bounces=4, seed=1)
+    monkeypatch.setenv("RTX_PRIMARIES_FIRST", "1")
+    c2 = rt.Context(0)
+    try:
+        c2.upload(s)
+        img, st2 = c2.render(spp=16, bounces=4, seed=1)
+        assert np.array_equal(img, ref), f"{(img != ref).any(axis=2).sum()} pixels differ"
+        assert (st2.primary_rays, st2.bounce_rays, st2.shadow_rays) == (st.primary_rays, st.bounce_rays, st.shadow_rays)
+    finally:
+        c2.close()
+
+
 def test_config4_scan_glass_deep_bounces(rt, orc, gpu):
     """Config 4 materials (mirror + glass + Phong compositions: binary bounce tree) on the
     full geometry; 512^2 so the verbatim traversal finishes in seconds."""
