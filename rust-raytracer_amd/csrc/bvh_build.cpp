@@ -5,8 +5,11 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <thread>
 
@@ -38,8 +41,67 @@ inline float surface_area(const float mn[3], const float mx[3]) {
     return 2.0f * dx * dy + 2.0f * dx * dz + 2.0f * dz * dy;
 }
 
-constexpr int kBuckets = 12;   // N_BUCKETS (bvh.rs:241)
+constexpr int kBuckets = kSahBuckets;
 constexpr uint32_t kLeaf = 4;  // BVH_LEAF_SIZE (bvh.rs:331)
+
+// bvh_split (bvh.rs:208-216): widest axis of the centroid range; y beats x, z beats the running maximum, only if
+// strictly greater
+inline int widest_axis(const float cmin[3], const float cmax[3]) {
+    float diff[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
+    int dim = 0;
+    float mx = diff[0];
+    if (diff[1] > mx) {
+        mx = diff[1];
+        dim = 1;
+    }
+    if (diff[2] > mx) dim = 2;
+    return dim;
+}
+
+// Rust `as i32` of trunc(12 (c - min) / range): NaN -> 0, saturating; 12 -> 11 (bvh.rs:254-260)
+inline int bucket_of(float c, float cmin_dim, float dim_range) {
+    float f = 12.0f * (c - cmin_dim) / dim_range;
+    float ft = std::trunc(f);
+    int bi;
+    if (!(ft == ft)) bi = 0;
+    else if (ft >= 2147483648.0f) bi = 2147483647;
+    else if (ft <= -2147483648.0f) bi = -2147483647 - 1;
+    else bi = (int)ft;
+    if (bi == kBuckets) bi -= 1;
+    return bi;
+}
+
+// bvh_split_by_sah's choice (bvh.rs:275-304): cost_i = 0.125 + (nL SA(L) + nR SA(R)) / SA(centroid box), strict <,
+// the first minimum wins
+inline int sah_choose(const uint32_t count[kBuckets], const Box bb[kBuckets], const float cmin[3], const float cmax[3]) {
+    float sa_global = surface_area(cmin, cmax);
+    float best_cost = 0.0f;
+    int best_i = 0;
+    for (int i = 0; i < kBuckets - 1; i++) {
+        Box l = bb[0], r = bb[i + 1];
+        float cl = 0.0f, cr = 0.0f;
+        for (int j = 0; j <= i; j++) {
+            for (int k = 0; k < 3; k++) {
+                l.mn[k] = std::fmin(l.mn[k], bb[j].mn[k]);
+                l.mx[k] = std::fmax(l.mx[k], bb[j].mx[k]);
+            }
+            cl += (float)count[j];
+        }
+        for (int j = i + 1; j < kBuckets; j++) {
+            for (int k = 0; k < 3; k++) {
+                r.mn[k] = std::fmin(r.mn[k], bb[j].mn[k]);
+                r.mx[k] = std::fmax(r.mx[k], bb[j].mx[k]);
+            }
+            cr += (float)count[j];
+        }
+        float cost = 0.125f + (cl * surface_area(l.mn, l.mx) + cr * surface_area(r.mn, r.mx)) / sa_global;
+        if (i == 0 || cost < best_cost) {  // strict <, first minimum wins (bvh.rs:296-304)
+            best_cost = cost;
+            best_i = i;
+        }
+    }
+    return best_i;
+}
 
 struct Ctx {
     const rtx_scene_desc &d;
@@ -89,14 +151,7 @@ void Ctx::build(uint32_t ni, uint32_t b, uint32_t e) {
             cmax[k] = std::fmax(cmax[k], c[k]);
         }
     }
-    float diff[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
-    int dim = 0;
-    float mx = diff[0];
-    if (diff[1] > mx) {
-        mx = diff[1];
-        dim = 1;
-    }
-    if (diff[2] > mx) dim = 2;
+    const int dim = widest_axis(cmin, cmax);
     // bvh_split_by_sah (bvh.rs:245-321); n > 4 here so the Basic branch is unreachable
     uint32_t count[kBuckets] = {0};
     Box bb[kBuckets];
@@ -105,14 +160,7 @@ void Ctx::build(uint32_t ni, uint32_t b, uint32_t e) {
     float dim_range = cmax[dim] - cmin[dim];
     for (uint32_t i = b; i < e; i++) {
         uint32_t o = idx[i];
-        float f = 12.0f * (cents[o][dim] - cmin[dim]) / dim_range;
-        float ft = std::trunc(f);
-        int bi;  // Rust `as i32`: NaN -> 0, saturating
-        if (!(ft == ft)) bi = 0;
-        else if (ft >= 2147483648.0f) bi = 2147483647;
-        else if (ft <= -2147483648.0f) bi = -2147483647 - 1;
-        else bi = (int)ft;
-        if (bi == kBuckets) bi -= 1;
+        const int bi = bucket_of(cents[o][dim], cmin[dim], dim_range);
         if (bi < 0 || bi >= kBuckets) {  // the reference's debug_assert / index panic
             degenerate.store(true);
             nd.left = nd.right = -1;
@@ -125,32 +173,7 @@ void Ctx::build(uint32_t ni, uint32_t b, uint32_t e) {
         }
         bucket[i] = (uint8_t)bi;
     }
-    float sa_global = surface_area(cmin, cmax);
-    float best_cost = 0.0f;
-    int best_i = 0;
-    for (int i = 0; i < kBuckets - 1; i++) {
-        Box l = bb[0], r = bb[i + 1];
-        float cl = 0.0f, cr = 0.0f;
-        for (int j = 0; j <= i; j++) {
-            for (int k = 0; k < 3; k++) {
-                l.mn[k] = std::fmin(l.mn[k], bb[j].mn[k]);
-                l.mx[k] = std::fmax(l.mx[k], bb[j].mx[k]);
-            }
-            cl += (float)count[j];
-        }
-        for (int j = i + 1; j < kBuckets; j++) {
-            for (int k = 0; k < 3; k++) {
-                r.mn[k] = std::fmin(r.mn[k], bb[j].mn[k]);
-                r.mx[k] = std::fmax(r.mx[k], bb[j].mx[k]);
-            }
-            cr += (float)count[j];
-        }
-        float cost = 0.125f + (cl * surface_area(l.mn, l.mx) + cr * surface_area(r.mn, r.mx)) / sa_global;
-        if (i == 0 || cost < best_cost) {  // strict <, first minimum wins (bvh.rs:296-304)
-            best_cost = cost;
-            best_i = i;
-        }
-    }
+    const int best_i = sah_choose(count, bb, cmin, cmax);
     // stable partition (bvh.rs:306-319)
     uint32_t nl = 0;
     for (uint32_t i = b; i < e; i++)
@@ -191,6 +214,122 @@ void Ctx::build(uint32_t ni, uint32_t b, uint32_t e) {
         me.mn[k] = std::fmin(L.mn[k], R.mn[k]);
         me.mx[k] = std::fmax(L.mx[k], R.mx[k]);
     }
+}
+
+static_assert(sizeof(Box) == 24 && sizeof(V3) == 12, "TopSplitter takes the boxes and centroids as packed floats");
+
+// TopSplitter on the host, single-threaded: the loops of Ctx::build behind the interface.
+struct HostTopSplitter : TopSplitter {
+    const Box *boxes = nullptr;
+    const V3 *cents = nullptr;
+    std::vector<uint32_t> idx, scratch;
+    std::vector<uint8_t> bucket;
+    bool begin(const float *b, const float *c, uint32_t n) override {
+        boxes = reinterpret_cast<const Box *>(b);
+        cents = reinterpret_cast<const V3 *>(c);
+        idx.resize(n);
+        for (uint32_t i = 0; i < n; i++) idx[i] = i;
+        scratch.resize(n);
+        bucket.resize(n);
+        return true;
+    }
+    bool centroid_range(uint32_t b, uint32_t e, float cmin[3], float cmax[3]) override {
+        const float big = std::numeric_limits<float>::max();
+        for (int k = 0; k < 3; k++) {
+            cmin[k] = big;
+            cmax[k] = -big;
+        }
+        for (uint32_t i = b; i < e; i++)
+            for (int k = 0; k < 3; k++) {
+                cmin[k] = std::fmin(cmin[k], cents[idx[i]][k]);
+                cmax[k] = std::fmax(cmax[k], cents[idx[i]][k]);
+            }
+        return true;
+    }
+    bool bin(uint32_t b, uint32_t e, int dim, float cmin_dim, float dim_range, uint32_t count[kBuckets], float bb[kBuckets][6],
+             bool *bad) override {
+        *bad = false;
+        for (int i = 0; i < kBuckets; i++) {
+            count[i] = 0;
+            for (int k = 0; k < 6; k++) bb[i][k] = 0.0f;
+        }
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t o = idx[i];
+            const int bi = bucket_of(cents[o][dim], cmin_dim, dim_range);
+            if (bi < 0 || bi >= kBuckets) {
+                *bad = true;
+                return true;
+            }
+            count[bi] += 1;
+            for (int k = 0; k < 3; k++) {
+                bb[bi][k] = std::fmin(bb[bi][k], boxes[o].mn[k]);
+                bb[bi][3 + k] = std::fmax(bb[bi][3 + k], boxes[o].mx[k]);
+            }
+            bucket[i] = (uint8_t)bi;
+        }
+        return true;
+    }
+    bool partition(uint32_t b, uint32_t e, int best_i) override {
+        uint32_t nl = 0;
+        for (uint32_t i = b; i < e; i++) nl += bucket[i] <= best_i;
+        uint32_t pl = b, pr = b + nl;
+        for (uint32_t i = b; i < e; i++) {
+            if (bucket[i] <= best_i) scratch[pl++] = idx[i];
+            else scratch[pr++] = idx[i];
+        }
+        std::copy(scratch.begin() + b, scratch.begin() + e, idx.begin() + b);
+        return true;
+    }
+    bool finish(uint32_t *out) override {
+        std::copy(idx.begin(), idx.end(), out);
+        return true;
+    }
+};
+
+// The top of the tree through a TopSplitter: nodes of at least `piece` objects are split breadth first (the same
+// decisions as Ctx::build, from the splitter's per-node results); what is left -- `frontier`, pieces of fewer
+// objects -- is for the host threads.  `tops` lists the split nodes in creation order (a parent before its
+// children).  Returns 1 done, 0 the splitter failed (nothing usable), -1 degenerate input.
+int split_top(Ctx &c, TopSplitter &top, uint32_t n, uint32_t piece, std::vector<std::array<uint32_t, 3>> &frontier,
+              std::vector<uint32_t> &tops) {
+    if (!top.begin(&c.boxes[0].mn[0], reinterpret_cast<const float *>(c.cents.data()), n)) return 0;
+    std::vector<std::array<uint32_t, 3>> todo{{0u, 0u, n}};
+    for (size_t at = 0; at < todo.size(); at++) {
+        const uint32_t ni = todo[at][0], b = todo[at][1], e = todo[at][2], cnt = e - b;
+        if (cnt < piece || cnt <= kLeaf) {
+            frontier.push_back(todo[at]);
+            continue;
+        }
+        BuildNode &nd = c.nodes[ni];
+        nd.first = b;
+        nd.count = cnt;
+        float cmin[3], cmax[3];
+        if (!top.centroid_range(b, e, cmin, cmax)) return 0;
+        const int dim = widest_axis(cmin, cmax);
+        uint32_t count[kBuckets];
+        float bbf[kBuckets][6];
+        bool bad = false;
+        if (!top.bin(b, e, dim, cmin[dim], cmax[dim] - cmin[dim], count, bbf, &bad)) return 0;
+        if (bad) return -1;
+        Box bb[kBuckets];
+        for (int i = 0; i < kBuckets; i++)
+            for (int k = 0; k < 3; k++) {
+                bb[i].mn[k] = bbf[i][k];
+                bb[i].mx[k] = bbf[i][3 + k];
+            }
+        const int best_i = sah_choose(count, bb, cmin, cmax);
+        uint32_t nl = 0;
+        for (int i = 0; i <= best_i; i++) nl += count[i];
+        if (nl == 0 || nl == cnt) return -1;
+        if (!top.partition(b, e, best_i)) return 0;
+        const uint32_t ci = c.next_node.fetch_add(2);
+        nd.left = (int32_t)ci;
+        nd.right = (int32_t)ci + 1;
+        tops.push_back(ni);
+        todo.push_back({ci, b, b + nl});
+        todo.push_back({ci + 1, b + nl, e});
+    }
+    return top.finish(c.idx.data()) ? 1 : 0;
 }
 
 uint32_t depth_of(const std::vector<BuildNode> &nodes, uint32_t root) {
@@ -235,7 +374,9 @@ void object_bounding_box(const rtx_scene_desc &d, uint32_t i, float mn[3], float
     }
 }
 
-int build_bvh(const rtx_scene_desc &d, int threads, BuiltBvh &out, std::string &err) {
+TopSplitter *new_host_top_splitter() { return new HostTopSplitter(); }
+
+int build_bvh(const rtx_scene_desc &d, int threads, BuiltBvh &out, std::string &err, TopSplitter *top, uint32_t top_min) {
     uint32_t n = d.n_objects;
     out.nodes.clear();
     out.leaf_order.clear();
@@ -276,9 +417,49 @@ int build_bvh(const rtx_scene_desc &d, int threads, BuiltBvh &out, std::string &
     c.scratch.resize(n);
     c.bucket.resize(n);
     c.nodes.resize((size_t)2 * n + 1);
-    c.spare_threads.store(threads - 1);
     c.par_threshold = std::max<uint32_t>(1u << 14, n / 256);
-    c.build(0, 0, n);
+    bool built = false;
+    if (top && n >= std::max<uint32_t>(top_min, 64u * (kLeaf + 1))) {
+        std::vector<std::array<uint32_t, 3>> frontier;
+        std::vector<uint32_t> tops;
+        uint32_t pieces = 64;
+        if (const char *tp = std::getenv("RTX_TOP_PIECES")) pieces = (uint32_t)std::max(2, std::atoi(tp));
+        const int rc = split_top(c, *top, n, std::max<uint32_t>(n / pieces, kLeaf + 1), frontier, tops);
+        if (rc < 0) c.degenerate.store(true);
+        if (rc > 0) {
+            // the pieces, largest first, on the host threads (each piece single-threaded: there are >= 64 of them)
+            std::sort(frontier.begin(), frontier.end(),
+                      [](const std::array<uint32_t, 3> &a, const std::array<uint32_t, 3> &b) { return a[2] - a[1] > b[2] - b[1]; });
+            c.spare_threads.store(0);
+            c.par_threshold = 0xFFFFFFFFu;
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++)
+                pool.emplace_back([&]() {
+                    for (size_t k = next.fetch_add(1); k < frontier.size(); k = next.fetch_add(1))
+                        c.build(frontier[k][0], frontier[k][1], frontier[k][2]);
+                });
+            for (auto &t : pool) t.join();
+            for (size_t k = tops.size(); k-- > 0;) {  // node box = union(left, right) (bvh.rs:353), children first
+                BuildNode &me = c.nodes[tops[k]];
+                const BuildNode &L = c.nodes[me.left], &R = c.nodes[me.right];
+                for (int a = 0; a < 3; a++) {
+                    me.mn[a] = std::fmin(L.mn[a], R.mn[a]);
+                    me.mx[a] = std::fmax(L.mx[a], R.mx[a]);
+                }
+            }
+        }
+        built = rc != 0;
+        if (rc == 0) {  // the splitter gave up (said aloud: the build is slower without it): nothing it did is kept
+            std::fprintf(stderr, "rtx: the top of the BVH could not be split on the GPU (allocation or launch failed); the host builds the whole tree\n");
+            for (uint32_t i = 0; i < n; i++) c.idx[i] = i;
+            c.next_node.store(1);
+        }
+    }
+    if (!built) {
+        c.spare_threads.store(threads - 1);
+        c.build(0, 0, n);
+    }
     if (c.degenerate.load()) {
         err = "BVH build cannot separate a set of more than 4 objects (identical centroids on the widest "
               "axis, or non-finite geometry); the reference recurses forever on this input (bvh.rs:221-230)";

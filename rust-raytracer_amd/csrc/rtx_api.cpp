@@ -18,6 +18,7 @@
 #include "../../include/rtx.h"
 #include "../../include/rtx_host.h"
 #include "bvh_build.h"
+#include "gpu_build.h"
 #include "flatten.h"
 #include "hostmath.h"
 #include "kernels.h"
@@ -92,6 +93,7 @@ struct rtx_ctx {
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
     uint32_t *h_noalloc_flag = nullptr;  // pinned word: CTR_OVERFLOW of the last rtx_render_device_noalloc (allocated by rtx_init)
     bool noalloc_pending = false;     // ... which nobody has looked at yet (rtx_synchronize / rtx_slot_synchronize(0) do)
+    int gpu_binning = -1;             // RTX_GPU_BINNING: 0 never, 1 from 4096 objects on, -1 = from 2^20 objects on
     int primaries_first = -1;         // RTX_PRIMARIES_FIRST: 0 never, 1 always, -1 = by batch size
     uint32_t primaries_first_below = 0;  // RTX_PRIMARIES_FIRST_BELOW: ... batches of fewer primaries per wave than this
     uint32_t stripe_blocks = 1;       // RTX_STRIPE_BLOCKS: 8x8 pixel blocks (with all their samples) per stripe of the queue of primaries
@@ -714,6 +716,7 @@ int rtx_init(int device, rtx_ctx **out) {
         return RTX_ERR_HIP;
     }
     *c->h_noalloc_flag = 0;
+    if (const char *gb = std::getenv("RTX_GPU_BINNING")) c->gpu_binning = std::atoi(gb) != 0;
     if (const char *pf = std::getenv("RTX_PRIMARIES_FIRST")) c->primaries_first = std::atoi(pf) != 0;
     if (const char *pb = std::getenv("RTX_PRIMARIES_FIRST_BELOW")) c->primaries_first_below = (uint32_t)std::max(0, std::atoi(pb));
     if (const char *sb = std::getenv("RTX_STRIPE_BLOCKS")) c->stripe_blocks = (uint32_t)std::min(1024, std::max(1, std::atoi(sb)));
@@ -783,7 +786,15 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if (const char *t = std::getenv("RTX_BUILD_THREADS")) threads = std::max(1, std::atoi(t));
     double t0 = now_s();
     BuiltBvh bvh;
-    int rc = build_bvh(*d, threads, bvh, c->err);
+    // GPU-assisted binning (gpu_build.hip): the nodes at the top of a big tree are split by kernels, the pieces by
+    // the host threads.  RTX_GPU_BINNING=0 / 1: never / for every scene of at least 4096 objects; default: from
+    // 2^20 objects on (below that the host's own top levels cost less than the transfer of the boxes)
+    int rc;
+    {
+        const int mode = c->gpu_binning;
+        std::unique_ptr<TopSplitter> top(mode != 0 ? new_gpu_top_splitter(c->device) : nullptr);
+        rc = build_bvh(*d, threads, bvh, c->err, top.get(), mode > 0 ? 4096u : 1u << 20);
+    }
     if (rc != RTX_OK) return rc;
     double t1 = now_s();
     FlatScene fs;
@@ -1275,7 +1286,12 @@ int rtx_host_bvh_digest(const rtx_scene_desc *d, int threads, uint32_t *leaf_ord
     if (!d) return RTX_ERR_INVALID;
     BuiltBvh bvh;
     std::string err;
-    int rc = build_bvh(*d, threads, bvh, err);
+    // RTX_TOP_SPLITTER=host: the top of the tree through the TopSplitter interface (its host implementation), as
+    // rtx_upload_scene runs it through the GPU one -- the CPU tests compare the two ways of building
+    std::unique_ptr<TopSplitter> top;
+    if (const char *ts = std::getenv("RTX_TOP_SPLITTER"))
+        if (std::string(ts) == "host") top.reset(new_host_top_splitter());
+    int rc = build_bvh(*d, threads, bvh, err, top.get(), 512u);
     if (rc != RTX_OK) {
         g_init_error = err;
         return rc;

@@ -82,6 +82,34 @@ def test_bvh_builder_is_thread_count_invariant(rt):
         assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and ref[2:] == got[2:]
 
 
+@pytest.mark.parametrize("name,param", [("soup", 60000), ("scan", 30000), ("random_spheres", 5000), ("scan_glass", 700)])
+def test_bvh_top_phase_through_the_splitter_interface(rt, monkeypatch, name, param):
+    """build_bvh with a TopSplitter (bvh_build.h): the nodes at the top are split breadth first from the splitter's
+    per-node ranges, bucket counts / boxes and stable partitions, the pieces by the host threads.  With the host
+    implementation of the interface (RTX_TOP_SPLITTER=host) the tree must be the plain recursion's, bit for bit --
+    the same driver runs the GPU implementation in rtx_upload_scene (tests/test_gpu_build.py)."""
+    s = rt.HostScene(name, 32, param)
+    ref = rt.host_bvh_digest(s, threads=4)
+    monkeypatch.setenv("RTX_TOP_SPLITTER", "host")
+    for t in (1, 5):
+        got = rt.host_bvh_digest(s, threads=t)
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and ref[2:] == got[2:]
+
+
+def test_bvh_top_phase_reports_degenerate_input(rt, monkeypatch):
+    """600 objects with one centroid cannot be separated at the root: the top phase must say so like the recursion."""
+    monkeypatch.setenv("RTX_TOP_SPLITTER", "host")
+    objs = [("sphere", (1, 2, 3), 0.5 + 0.001 * i) for i in range(600)]
+    with pytest.raises(rt.RtxError) as e:
+        rt.host_bvh_digest(rt.ArrayScene(objs))
+    assert e.value.status == rt.RTX_ERR_DEGENERATE
+    # ... and further down, in a piece that the host threads build: a cluster of 40 inside 2000 separable objects
+    objs = [("sphere", (float(i % 50), float(i // 50), 0.0), 0.3) for i in range(2000)] + [("sphere", (7.25, 3.25, 1.0), 0.1 + 0.001 * i) for i in range(40)]
+    with pytest.raises(rt.RtxError) as e:
+        rt.host_bvh_digest(rt.ArrayScene(objs))
+    assert e.value.status == rt.RTX_ERR_DEGENERATE
+
+
 def test_bvh_digests_match_golden(rt):
     for key, (name, param) in {"bvh_suzanne_0": ("suzanne", 0), "bvh_soup_10000": ("soup", 10000),
                                "bvh_scan_100000": ("scan", 100000)}.items():

@@ -14,5 +14,5 @@ if [ -n "$HOSTDEFS" ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $HOSTDEFS -c rtx_api.cpp -o /tmp/rtx_api_$name.o
   api=/tmp/rtx_api_$name.o
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../gpurun_variants/librtx_$name.so /tmp/kernels_$name.o $api bvh_build.o flatten.o host_scene.o host_io.o scene_file.o -lz -lpthread -lrccl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../gpurun_variants/librtx_$name.so /tmp/kernels_$name.o $api gpu_build.o bvh_build.o flatten.o host_scene.o host_io.o scene_file.o -lz -lpthread -lrccl
 echo built $name
