@@ -14,6 +14,14 @@ int main() {
         rtx::FlatScene fs;
         int rc2 = rtx::flatten_scene(*d, bvh, fs, err, 8);
         std::printf("%s: build %d flatten %d nodes %zu wide %zu prims %zu\n", name, rc, rc2, fs.nodes.size(), fs.wnodes.size(), fs.prims.size());
+        // the same tree with its top split through the TopSplitter interface and the pieces built by a pool of 8 threads
+        rtx::BuiltBvh bvh2;
+        rtx::TopSplitter *top = rtx::new_host_top_splitter();
+        int rc3 = rtx::build_bvh(*d, 8, bvh2, err, top, 512u);
+        delete top;
+        bool same = rc3 == rc && bvh2.leaf_order == bvh.leaf_order && bvh2.depth == bvh.depth && bvh2.nodes.size() == bvh.nodes.size();
+        std::printf("%s: top phase + pieces %d, same tree: %s\n", name, rc3, same ? "yes" : "NO");
+        if (!same) return 1;
         rtx_scene_free(s);
     }
     return 0;
