@@ -25,6 +25,7 @@ struct FlatScene {
     uint32_t root_ref = NO_PRIM;
     float root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     uint32_t n_leaves = 0;
+    bool any_xform = false;             // more than an eighth of the objects have a transform of their own
     bool xf0_identity = false;          // transform 0 is exactly the identity matrix pair
     uint32_t max_bounce = 0;            // largest number of bounce leaves of any material in use
     float total_sa = 0.0f;              // BvhTree::total_sa (bvh.rs:419-426)

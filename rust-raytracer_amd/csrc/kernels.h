@@ -108,6 +108,7 @@ struct LaunchCfg {
     bool count_visits;
     bool reference_traversal;
     bool leaf_bank = false;  // the path kernel variant that sets leaves aside during node steps (kernels.hip, wave_step)
+    bool xform_cache = false;  // scenes where many objects have transforms: the kernel variant that keeps the ray in the last transform's space (kernels.hip, RayCtx)
     bool primaries_first = false;  // trace the primaries alone, then the rest from their hits, bounce materials first (launch_path)
 };
 

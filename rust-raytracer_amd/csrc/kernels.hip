@@ -143,6 +143,10 @@ __device__ __forceinline__ uint32_t jitter_u32(uint32_t seed_lo, uint32_t seed_h
 
 // ---------------------------------------------------------------- wave-level queue allocation
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+// set bits of `m` below this lane (v_mbcnt: no lane mask kept in registers)
+__device__ __forceinline__ uint32_t rank_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // Queue head of a persistent kernel: lane 0 takes `n` work items, the wave shares the base.
 __device__ __forceinline__ uint32_t wave_fetch(uint32_t *head, uint32_t n) {
@@ -155,7 +159,13 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t *head, uint32_t n) {
 struct RayCtx {
     F3 o, d;        // world ray (d normalised by Ray::new)
     F3 inv;         // 1/d, correctly rounded
-    F3 oo, od;      // the ray in the object space of xform `xf` (ray.rs:18-23)
+    // The ray in object space (ray.rs:18-23), two ways (template parameter XFC of the kernels; the host picks):
+    // XFC = false, scenes whose objects all have the identity transform (meshes: the headline scene, the soup): the
+    //   origin is o, and od is the direction normalised once more, as Ray::new does -- 4 registers and a branch per
+    //   test less than a cache: -3 % on the headline frame; an object with a transform gets its ray per test (+4 % on
+    //   the Suzanne scene, hence:)
+    // XFC = true, scenes with transforms: (oo, od) is the ray in the space of transform `xf`, the last one a test needed.
+    F3 oo, od;
     uint32_t xf;
     bool exact_only;  // a zero / non-finite component, or slab products that could overflow: always take the division path
     float slack0;     // absolute pruning slack
@@ -169,20 +179,10 @@ struct RayCtx {
     }
 };
 
-// `identity`: both matrices of the transform are exactly the identity; M*(p,1) and M*(v,0)
-// then reproduce p and v bit for bit (x*1 + y*0 + z*0 + 0), so the products are skipped.
-__device__ __forceinline__ void set_xform(RayCtx &r, const Xform *xforms, uint32_t xf, bool identity) {
-    if (identity) {
-        r.oo = r.o;
-        r.od = normalize(r.d);
-    } else {
-        const float *M = xforms[xf].w2o;
-        r.oo = transform_point(M, r.o);
-        r.od = normalize(transform_vector(M, r.d));
-    }
-    r.xf = xf;
-}
-
+// Object space of an identity transform: M*(p,1) and M*(v,0) reproduce p and v bit for bit (x*1 + y*0 + z*0 + 0), so
+// the products are skipped; Ray::new normalises the direction again (ray.rs:14), which changes a unit vector's last
+// bits more often than not.
+template <bool XFC>
 __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o, F3 d) {
     r.o = o;
     r.d = d;
@@ -215,7 +215,12 @@ __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o,
     if (!(fabsf(dot(d, d) - 1.0f) <= 4e-6f)) r.slack0 = INFINITY;
     // (Hits that lie outside their object's box -- non-planar quads, sheared spheres -- are
     // allowed for per node slot, see node_step.)
-    set_xform(r, sc.xforms, 0, sc.xf0_identity != 0u);
+    if constexpr (XFC) {
+        r.xf = 0xFFFFFFFFu;  // (no transform yet: the first test computes its own)
+        r.oo = r.od = f3(0.f, 0.f, 0.f);
+    } else {
+        r.od = normalize(d);
+    }
 }
 
 // AABB::intersect decision exactly as bvh.rs:60-131 (true divisions, Interval algebra in
@@ -301,14 +306,37 @@ __device__ __forceinline__ bool box_test(float mnx, float mny, float mnz, float 
 }
 
 // Object::get_intersection (object.rs:145-220) against one 64-byte primitive record.
+template <bool XFC>
 __device__ __forceinline__ bool prim_intersect(const Prim *pp, RayCtx &r, const Xform *xforms, float &t_world) {
     const float4 *q4 = reinterpret_cast<const float4 *>(pp);
     float4 p0 = q4[0], p1 = q4[1], p2 = q4[2], p3 = q4[3];
     uint32_t meta = __float_as_uint(p3.w);
     uint32_t type = meta & 3u, xf = (meta >> 2) & 0x1FFFu;
     const bool identity = (meta & PRIM_IDENTITY_XFORM) != 0u;
-    if (xf != r.xf) set_xform(r, xforms, xf, identity);
-    F3 position = r.oo, direction = r.od;
+    F3 position, direction;
+    if constexpr (XFC) {
+        if (xf != r.xf) {
+            if (identity) {
+                r.oo = r.o;
+                r.od = normalize(r.d);
+            } else {
+                const float *M = xforms[xf].w2o;
+                r.oo = transform_point(M, r.o);
+                r.od = normalize(transform_vector(M, r.d));
+            }
+            r.xf = xf;
+        }
+        position = r.oo;
+        direction = r.od;
+    } else {
+        position = r.o;
+        direction = r.od;
+        if (!identity) {  // ray.transform_using(world_to_object) (object.rs:146-148, ray.rs:18-23)
+            const float *M = xforms[xf].w2o;
+            position = transform_point(M, r.o);
+            direction = normalize(transform_vector(M, r.d));
+        }
+    }
     float t;
     bool hit = false;
     if (type == 0u) {  // Sphere: centre p0.xyz, radius p0.w, radius^2 p1.x
@@ -662,14 +690,14 @@ __device__ __forceinline__ void node_step(const DeviceScene &sc, Trav &s, Stack 
 // Advances a lane that holds a leaf by ONE primitive (Vec order, bvh.rs:378-389): the leaf
 // reference (first << 3 | count) shrinks from the front until it is used up.  The banked leaf
 // goes first (it was reached first); only the leaf in `cur` is followed by a pop.
-template <bool COUNT, bool REF>
+template <bool COUNT, bool REF, bool XFC>
 __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow) {
     const bool banked = s.bank != TRAV_DONE;
     uint32_t cur = banked ? s.bank : s.cur;
     uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
     float tw;
     if (COUNT) s.prims++;
-    if (prim_intersect(sc.prims + first, s.r, sc.xforms, tw)) {
+    if (prim_intersect<XFC>(sc.prims + first, s.r, sc.xforms, tw)) {
         if (!shadow) {
             if (!s.any || tw < s.t || (tw == s.t && first < s.prim)) {
                 s.any = true;
@@ -709,7 +737,7 @@ __device__ __forceinline__ void prim_step(const DeviceScene &sc, Trav &s, Stack 
 // kernel is bound by VALU issue (a 20M-triangle soup: -9 % of the frame time), and costs 3-6 % where
 // rays are short -- as a run-time switch inside one kernel it cost the short-ray scenes the same
 // (registers and code in the stepping loop, not the extra visits).  The host picks per scene.
-template <bool COUNT, bool REF, bool OVH, bool BANK>
+template <bool COUNT, bool REF, bool OVH, bool BANK, bool XFC>
 __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack &st, bool shadow, LdsNodePtr lds_top,
                                           Util &u) {
     const bool cur_leaf = (s.cur & LEAF_BIT) && s.cur != TRAV_DONE;
@@ -729,7 +757,7 @@ __device__ __forceinline__ void wave_step(const DeviceScene &sc, Trav &s, Stack 
         u.prim_steps++;
         u.prim_lanes += nl;
 #endif
-        if (at_leaf) prim_step<COUNT, REF>(sc, s, st, shadow);
+        if (at_leaf) prim_step<COUNT, REF, XFC>(sc, s, st, shadow);
     } else {
         if (bankable) {
             s.bank = s.cur;
@@ -1036,7 +1064,7 @@ __device__ __forceinline__ void ray_hist(uint32_t *ctr, uint32_t cls, uint32_t r
     atomicAdd(ctr + CTR_WORDS + 128u + cls * 16u + b, records);
 }
 #endif
-template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK, bool PRE>
+template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK, bool PRE, bool XFC>
 __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
     __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
@@ -1052,7 +1080,6 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     const uint32_t nthreads = gridDim.x * TBLOCK;
     const uint32_t gtid = blockIdx.x * TBLOCK + threadIdx.x;
     const uint32_t lane = lane_id();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     Stack st;
     st.lds = (LdsStackPtr)(lds_stack + threadIdx.x);
     st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
@@ -1122,7 +1149,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             const unsigned long long t_s0 = wall_clock64();
 #endif
             do {
-                wave_step<COUNT, REF, OVH, BANK>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
+                wave_step<COUNT, REF, OVH, BANK, XFC>(sc, s, st, (tag & WK_SHADOW) != 0u, lds_top, util);
                 steps_run++;
             } while ((uint32_t)__popcll(__ballot(s.done())) < stop_at);
 #ifdef RTX_UTIL_STATS
@@ -1203,7 +1230,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 // hits wait in the wave's shading list until enough of them make a full-width pass
                 const bool hitc = finc && s.any;
                 const unsigned long long hm = __ballot(hitc);
-                if (hitc) wsh[shn + (uint32_t)__popcll(hm & lt_mask)] = make_uint2(node, tag >> WK_LEVEL_SHIFT);
+                if (hitc) wsh[shn + rank_below(hm)] = make_uint2(node, tag >> WK_LEVEL_SHIFT);
                 shn += (uint32_t)__popcll(hm);
             }
             if (fin) tag &= ~WK_BUSY;
@@ -1213,7 +1240,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         // want a shadow query, the bounce children; run by the idle lanes once SHADE_MIN hits wait
         if constexpr (SHADE) {
             if (shn >= (uint32_t)RTX_SHADE_MIN || shn > (uint32_t)SHADE_LIST - 64u || (shn != 0u && wq.exhausted && top < nidle)) {
-                const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
+                const uint32_t rank = rank_below(idlem);
                 const uint32_t n_sh = nidle < shn ? nidle : shn;
 #ifdef RTX_UTIL_STATS
                 util.shade_events++;
@@ -1252,7 +1279,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                         continue;
                     }
                     if (wl)
-                        wk[top + (uint32_t)__popcll(m & lt_mask)] =
+                        wk[top + rank_below(m)] =
                             make_uint2(hnode, l | (sc.lights[l].type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
                                                   (level << WK_LEVEL_SHIFT));
                     top += cnt;
@@ -1263,8 +1290,8 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 const unsigned long long b0 = __ballot(nb & 1u), b1 = __ballot(nb & 2u), b2 = __ballot(nb & 4u);
                 if ((b0 | b1 | b2) != 0ull) {
                     const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-                    const uint32_t before = (uint32_t)__popcll(b0 & lt_mask) + 2u * (uint32_t)__popcll(b1 & lt_mask) +
-                                            4u * (uint32_t)__popcll(b2 & lt_mask);
+                    const uint32_t before = rank_below(b0) + 2u * rank_below(b1) +
+                                            4u * rank_below(b2);
                     if (run_next + total > run_end) {
                         // the rest of the old run becomes holes, a new run is reserved with ONE atomic
                         for (uint32_t h = run_next + lane; h < run_end; h += 64u)
@@ -1308,7 +1335,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         RTX_SECTION(1)
         // ---- work for the idle lanes: the top of the wave's stack first, then new primaries
         {
-            const uint32_t rank = (uint32_t)__popcll(idlem & lt_mask);
+            const uint32_t rank = rank_below(idlem);
             const uint32_t n_pop = nidle < top ? nidle : top;
             bool got = false;
             if (idle && rank < n_pop) {
@@ -1380,7 +1407,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                     if (SHADE) fr.link[node] = make_uint2(0u, NO_PRIM);
                     tag = 0;
                 } else {
-                    init_ray(s.r, sc, ro, rd);
+                    init_ray<XFC>(s.r, sc, ro, rd);
                     s.t = dist;
                     trav_begin<REF, OVH>(sc, s, st);  // (a ray that misses the root box is done at once)
                 }
@@ -1454,15 +1481,15 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     }
 }
 
-template <bool COUNT, bool REF, bool SHADE, bool BANK = false, bool PRE = false>
+template <bool COUNT, bool REF, bool SHADE, bool BANK = false, bool PRE = false, bool XFC = false>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, REF, false, SHADE, BANK, PRE>(sc, fr, max_levels);
+    path_body<COUNT, REF, false, SHADE, BANK, PRE, XFC>(sc, fr, max_levels);
 }
 // The production traversal for scenes whose hits can lie outside their objects' boxes
 // (DeviceScene::overhang != 0): the per-slot allowance of node_step is compiled in here only.
-template <bool COUNT, bool SHADE, bool PRE = false>
+template <bool COUNT, bool SHADE, bool PRE = false, bool XFC = false>
 __global__ void __launch_bounds__(TBLOCK, RTX_TRACE_WAVES) path_ovh_kernel(DeviceScene sc, Frame fr, uint32_t max_levels) {
-    path_body<COUNT, false, true, SHADE, false, PRE>(sc, fr, max_levels);
+    path_body<COUNT, false, true, SHADE, false, PRE, XFC>(sc, fr, max_levels);
 }
 
 // ---------------------------------------------------------------- primaries first: the list of primary hits
@@ -1833,35 +1860,43 @@ void launch_load_rays(const Frame &fr, const float *org_dir, uint32_t n, const L
 void launch_path(const DeviceScene &sc, const Frame &fr, uint32_t max_levels, bool shade, const LaunchCfg &lc, uint32_t n0) {
     dim3 g(std::max(1, lc.persistent_blocks * BLOCK / TBLOCK)), b(TBLOCK);
 #define RTX_LAUNCH_PATH(K) hipLaunchKernelGGL(K, g, b, 0, lc.stream, sc, fr, max_levels)
+    // lc.xform_cache: the variant that keeps the ray in the object space of the last transform a test needed (RayCtx);
+    // the verbatim and the leaf-banking kernels exist without it only (their scenes are checked / are plain meshes)
+#define RTX_LAUNCH_XFC(...)                                           \
+    do {                                                              \
+        if (lc.xform_cache) RTX_LAUNCH_PATH((__VA_ARGS__, true>));   \
+        else RTX_LAUNCH_PATH((__VA_ARGS__, false>));                 \
+    } while (0)
+    const bool ovh = sc.overhang != 0.0f;
     if (shade && lc.primaries_first && !lc.reference_traversal && !lc.count_visits && !lc.leaf_bank && fr.preq && fr.pre_blocks && n0 != 0u) {
-        const bool ovh = sc.overhang != 0.0f;
-        if (ovh) RTX_LAUNCH_PATH((path_ovh_kernel<false, false>));
-        else RTX_LAUNCH_PATH((path_kernel<false, false, false>));
+        if (ovh) RTX_LAUNCH_XFC(path_ovh_kernel<false, false, false);
+        else RTX_LAUNCH_XFC(path_kernel<false, false, false, false, false);
         const uint32_t nblocks = (n0 + (uint32_t)PRE_SEG - 1u) / (uint32_t)PRE_SEG;
         hipLaunchKernelGGL(pre_count_kernel, dim3(nblocks), dim3(BLOCK), 0, lc.stream, sc, fr, n0);
         hipLaunchKernelGGL(pre_scan_kernel, dim3(1), dim3(1024), 0, lc.stream, fr, nblocks);
         hipLaunchKernelGGL(pre_scatter_kernel, dim3(nblocks), dim3(BLOCK), 0, lc.stream, fr, n0);
-        if (ovh) RTX_LAUNCH_PATH((path_ovh_kernel<false, true, true>));
-        else RTX_LAUNCH_PATH((path_kernel<false, false, true, false, true>));
+        if (ovh) RTX_LAUNCH_XFC(path_ovh_kernel<false, true, true);
+        else RTX_LAUNCH_XFC(path_kernel<false, false, true, false, true);
         return;
     }
     if (!shade) {  // closest hits of the primaries only (no visit counters on this path)
         if (lc.reference_traversal) RTX_LAUNCH_PATH((path_kernel<false, true, false>));
-        else if (sc.overhang != 0.0f) RTX_LAUNCH_PATH((path_ovh_kernel<false, false>));
-        else RTX_LAUNCH_PATH((path_kernel<false, false, false>));
+        else if (ovh) RTX_LAUNCH_XFC(path_ovh_kernel<false, false, false);
+        else RTX_LAUNCH_XFC(path_kernel<false, false, false, false, false);
     } else if (lc.reference_traversal) {
         if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, true, true>));
         else RTX_LAUNCH_PATH((path_kernel<false, true, true>));
-    } else if (sc.overhang != 0.0f) {
-        if (lc.count_visits) RTX_LAUNCH_PATH((path_ovh_kernel<true, true>));
-        else RTX_LAUNCH_PATH((path_ovh_kernel<false, true>));
+    } else if (ovh) {
+        if (lc.count_visits) RTX_LAUNCH_XFC(path_ovh_kernel<true, true, false);
+        else RTX_LAUNCH_XFC(path_ovh_kernel<false, true, false);
     } else if (lc.leaf_bank) {
         if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, false, true, true>));
         else RTX_LAUNCH_PATH((path_kernel<false, false, true, true>));
     } else {
-        if (lc.count_visits) RTX_LAUNCH_PATH((path_kernel<true, false, true>));
-        else RTX_LAUNCH_PATH((path_kernel<false, false, true>));
+        if (lc.count_visits) RTX_LAUNCH_XFC(path_kernel<true, false, true, false, false);
+        else RTX_LAUNCH_XFC(path_kernel<false, false, true, false, false);
     }
+#undef RTX_LAUNCH_XFC
 #undef RTX_LAUNCH_PATH
 }
 void launch_resolve(const DeviceScene &sc, const Frame &fr, uint32_t level, const LaunchCfg &lc) {

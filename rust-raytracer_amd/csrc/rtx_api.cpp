@@ -93,6 +93,8 @@ struct rtx_ctx {
     uint32_t min_batches = 1;         // RTX_MIN_BATCHES: cut big frames into at least this many batches
     uint32_t *h_noalloc_flag = nullptr;  // pinned word: CTR_OVERFLOW of the last rtx_render_device_noalloc (allocated by rtx_init)
     bool noalloc_pending = false;     // ... which nobody has looked at yet (rtx_synchronize / rtx_slot_synchronize(0) do)
+    bool any_xform = false;           // many objects of the uploaded scene have a transform (flatten.cpp): LaunchCfg::xform_cache
+    int xform_cache_force = -1;       // RTX_XFORM_CACHE=0/1: force the kernel variant without / with the transform cache (tests; results are identical)
     int gpu_binning = -1;             // RTX_GPU_BINNING: 0 never, 1 from 4096 objects on, -1 = from 2^20 objects on
     int primaries_first = -1;         // RTX_PRIMARIES_FIRST: 0 never, 1 always, -1 = by batch size
     uint32_t primaries_first_below = 0;  // RTX_PRIMARIES_FIRST_BELOW: ... batches of fewer primaries per wave than this
@@ -573,6 +575,7 @@ int render_impl(rtx_ctx *c, uint32_t slot, uint32_t spp, uint32_t bounces, uint6
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{pp.main, c->persistent_blocks, (flags & RTX_FLAG_COUNT_VISITS) != 0,
                  (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    lc.xform_cache = c->any_xform;
     // Leaf banking pays where rays are long and the kernel is bound by VALU issue: measured -9 % on the
     // 20M-triangle soup, +-0 on the 4M one (bound by fabric reads), +3..6 % on the scenes of a few
     // million primitives and less.  RTX_LEAF_BANK=0/1 overrides the size rule.
@@ -716,6 +719,7 @@ int rtx_init(int device, rtx_ctx **out) {
         return RTX_ERR_HIP;
     }
     *c->h_noalloc_flag = 0;
+    if (const char *xc = std::getenv("RTX_XFORM_CACHE")) c->xform_cache_force = std::atoi(xc) != 0;
     if (const char *gb = std::getenv("RTX_GPU_BINNING")) c->gpu_binning = std::atoi(gb) != 0;
     if (const char *pf = std::getenv("RTX_PRIMARIES_FIRST")) c->primaries_first = std::atoi(pf) != 0;
     if (const char *pb = std::getenv("RTX_PRIMARIES_FIRST_BELOW")) c->primaries_first_below = (uint32_t)std::max(0, std::atoi(pb));
@@ -828,6 +832,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     ds.root_ref = fs.root_ref;
     ds.wroot_ref = fs.wide_root_ref;
     ds.xf0_identity = fs.xf0_identity ? 1u : 0u;
+    c->any_xform = c->xform_cache_force < 0 ? fs.any_xform : c->xform_cache_force != 0;
     float scale = 0.0f;
     for (int k = 0; k < 3; k++) {
         ds.root_mn[k] = fs.root_mn[k];
@@ -981,6 +986,7 @@ int rtx_render_device_noalloc(rtx_ctx *c, uint32_t spp, uint32_t bounces, uint64
     np.main = c->stream;
     flags |= c->force_flags;
     LaunchCfg lc{c->stream, blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    lc.xform_cache = c->any_xform;
     BatchInfo info{};
     info.q0 = 0;
     info.npix = (uint32_t)pt.npix;
@@ -1170,6 +1176,7 @@ int rtx_trace_primary(rtx_ctx *c, uint32_t sample, int use_jitter, uint64_t seed
     if (rc != RTX_OK) return rc;
     flags |= c->force_flags;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    lc.xform_cache = c->any_xform;
     DevBuf b_obj, b_t;
     HIP_TRY(c, b_obj.alloc(chunk * 4));
     HIP_TRY(c, b_t.alloc(chunk * 4));
@@ -1238,6 +1245,7 @@ static int rays_impl(rtx_ctx *c, const float *org_dir, uint64_t n, uint32_t flag
     int rc = ensure_frame(c, pp, chunk, std::max(levels, 1u));
     if (rc != RTX_OK) return rc;
     LaunchCfg lc{c->stream, c->persistent_blocks, false, (flags & RTX_FLAG_REFERENCE_TRAVERSAL) != 0};
+    lc.xform_cache = c->any_xform;
     DevBuf b_rays, b_f, b_obj;
     HIP_TRY(c, b_rays.alloc(chunk * 24));
     HIP_TRY(c, b_f.alloc(chunk * 12));

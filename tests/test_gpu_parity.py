@@ -522,6 +522,30 @@ def test_primaries_first_launch_is_exact(rt, monkeypatch, name, width, param, sp
     if name == "basic": assert stats[1].batches >= 2
 
 
+@pytest.mark.parametrize("name,width,param,spp", [("basic_suzanne", 160, 0, 2), ("scan", 128, 30000, 2), ("random_spheres", 128, 300, 2),
+                                                  ("basic", 96, 0, 1)])
+def test_transform_cache_variants_are_exact(rt, monkeypatch, name, width, param, spp):
+    """The path kernels come with and without a cache of the ray in the last transform's object space (kernels.hip,
+    RayCtx; the host picks by whether any object has a transform).  Forced either way (RTX_XFORM_CACHE), scenes with
+    and without transforms must give the same bytes, ray counts and primary hits."""
+    s = rt.HostScene(name, width, param)
+    out = []
+    for xc in ("0", "1"):
+        monkeypatch.setenv("RTX_XFORM_CACHE", xc)
+        c = rt.Context(0)
+        try:
+            c.upload(s)
+            img, st = c.render(spp=spp, bounces=4, seed=2)
+            obj, t = c.trace_primary()
+            out.append((img, st, obj, t))
+        finally:
+            c.close()
+    (i0, s0, o0, t0), (i1, s1, o1, t1) = out
+    assert i0.any() and np.array_equal(i0, i1)
+    assert (s0.primary_rays, s0.bounce_rays, s0.shadow_rays) == (s1.primary_rays, s1.bounce_rays, s1.shadow_rays)
+    assert np.array_equal(o0, o1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+
+
 def test_errors(rt, gpu):
     c = rt.Context(0)
     with pytest.raises(rt.RtxError) as e:
