@@ -3,7 +3,10 @@
 cd "$(dirname "$0")/.."
 G=gpurun_out; P=profiles
 cpif () { [ -f "$1" ] && cp "$1" "$2"; }
-for n in sq1 sq2 tcc1 tcc2 tcp1 tcp2 grbm fetch write; do cpif $G/pmc_headline/${n}_counter_collection.csv $P/r03_pmc_headline_$n.csv; done
+# (the rows of the trace path's kernels only: the same passes also see the scene upload's build kernels and copies)
+for n in sq1 sq2 tcc1 tcc2 tcp1 tcp2 grbm fetch write; do
+  [ -f $G/pmc_headline/${n}_counter_collection.csv ] && { head -1 $G/pmc_headline/${n}_counter_collection.csv; grep -E '"(void )?rtx::\(anonymous namespace\)::(path_kernel|path_ovh_kernel|resolve_kernel|raygen_kernel|accumulate_kernel)' $G/pmc_headline/${n}_counter_collection.csv; } > $P/r03_pmc_headline_$n.csv
+done
 cpif $G/pmc_headline/summary.txt $P/r03_pmc_summary.txt
 for t in config1 config2 config4 config5 soup4m; do cpif $G/pmc_$t/summary.txt $P/r03_pmc_${t}_summary.txt; done
 cpif $G/r03/kernel_stats.csv $P/r03_kernel_stats.csv
