@@ -97,6 +97,11 @@ struct LightRec {
     // Cone lights: cos of (cut-off - 8.01 degrees): inside that, the falloff's cone factor clamp((cut-off -
     // angle) / 8, 0, 1) is exactly 1 (light.rs:65-77) and the atan2 behind it need not run; 2 = never.
     float cos_full;
+    // Directional lights: the direction of the shadow query, Ray::new(point, -direction).offset(1e-4)
+    // (light.rs:109-110, ray.rs:11-16,43-46): ndir1 = normalize(-direction) moves the origin, ndir2 = normalize(ndir1)
+    // is the ray's direction -- two square roots and two divisions per query that depend on the light alone, done
+    // once by the flattener in the same f32 operations.
+    float ndir1[3], ndir2[3];
 };
 
 enum : uint32_t { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTIONAL = 2, LIGHT_CONE = 3 };  // light.rs:12-17
@@ -105,9 +110,10 @@ constexpr int MAX_LIGHTS = 16;
 constexpr int MAX_BOUNCE_LEAVES = 4;   // bounce leaves per material
 constexpr int MAX_COMP_DEPTH = 4;      // nesting of Composition
 #ifndef RTX_LDS_STACK
-#define RTX_LDS_STACK 14
+#define RTX_LDS_STACK 12
 #endif
-constexpr int LDS_STACK = RTX_LDS_STACK;          // per-lane traversal stack entries kept in LDS
+constexpr int LDS_STACK = RTX_LDS_STACK;          // per-lane traversal stack entries kept in LDS (the host sizes the spill for this, the smaller number)
+constexpr int LDS_STACK_DEEP = RTX_LDS_STACK + 2; // ... in the kernel variants for scenes of long rays, which list their waiting hits in global memory instead of LDS
 constexpr int MAX_TREE_DEPTH = 200;    // LDS_STACK + global spill entries per lane
 
 }  // namespace rtx

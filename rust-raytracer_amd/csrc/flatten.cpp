@@ -346,6 +346,10 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
         m.prog_count = (uint32_t)out.prog.size() - m.prog_first;
         m.n_bounce = nb;
         mat_bounce[i] = nb;
+        if (nb != 0u) {
+            if (out.bounce_mat_lo > out.bounce_mat_hi) out.bounce_mat_lo = out.bounce_mat_hi = i;
+            out.bounce_mat_hi = i;
+        }
         if (d.mat_tex_kind[i] < RTX_TEX_NONE || d.mat_tex_kind[i] > RTX_TEX_IMAGE) {
             err = "unknown texture kind";
             return RTX_ERR_INVALID;
@@ -400,6 +404,17 @@ int flatten_scene(const rtx_scene_desc &d, const BuiltBvh &bvh, FlatScene &out, 
             else l.cos_cut = (float)std::cos((double)cut);
             const double full = (double)l.angle_deg - 8.01;  // degrees
             l.cos_full = (full == full && full > 1.0 && full < 89.0) ? (float)std::cos(full * 3.14159265358979323846 / 180.0) : 2.0f;
+        }
+        {   // normalize(v) = v * (1 / sqrt((x x + y y) + z z)), as cgmath and the kernels evaluate it
+            auto norm3 = [](const float *v, float *o) {
+                const float m = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]), s = 1.0f / m;
+                o[0] = v[0] * s;
+                o[1] = v[1] * s;
+                o[2] = v[2] * s;
+            };
+            const float neg[3] = {-l.dir[0], -l.dir[1], -l.dir[2]};
+            norm3(neg, l.ndir1);
+            norm3(l.ndir1, l.ndir2);
         }
     }
     lap("tables");

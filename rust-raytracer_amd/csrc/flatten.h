@@ -28,6 +28,7 @@ struct FlatScene {
     bool any_xform = false;             // more than an eighth of the objects have a transform of their own
     bool xf0_identity = false;          // transform 0 is exactly the identity matrix pair
     uint32_t max_bounce = 0;            // largest number of bounce leaves of any material in use
+    uint32_t bounce_mat_lo = 1, bounce_mat_hi = 0;  // range of the material ids that have bounce leaves (empty: lo > hi)
     float total_sa = 0.0f;              // BvhTree::total_sa (bvh.rs:419-426)
     bool nonfinite_boxes = false;       // some node box has a NaN / infinite coordinate: the kernels then decide every box by the reference's divisions
     float overhang = 0.0f;              // how far a hit point can lie outside its object's reference box (flatten.cpp)

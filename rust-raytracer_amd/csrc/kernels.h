@@ -17,10 +17,11 @@ struct DeviceScene {
     const MatInstr *prog;
     const TextureRec *tex;
     const uint8_t *tex_data;
-    const LightRec *lights;
+    const LightRec *lights;     // per-lane look-ups (a shadow query's light)
     const uint32_t *prim_obj;   // leaf-order primitive -> object index of the description
     uint32_t n_prims, n_lights, n_wnodes;
     uint32_t max_bounce;        // most bounce children any material spawns per hit
+    uint32_t bounce_mat_lo, bounce_mat_hi;  // the material ids with bounce leaves lie in [lo, hi] (empty: lo > hi)
     uint32_t root_ref;          // child-reference encoding; NO_PRIM for an empty scene
     uint32_t wroot_ref;         // root in the wide tree (wide node 0 or the root leaf)
     uint32_t xf0_identity;      // transform 0 is exactly the identity
@@ -30,6 +31,11 @@ struct DeviceScene {
     float background[3];
     float c2w[16];
     uint32_t width, height;
+    // The lights again, inside the kernel arguments: a loop over the lights whose counter is the same in every lane
+    // reads them with scalar loads from the argument segment (through `lights` the compiler must assume that a
+    // store may have changed them: one vector-memory round trip per light and per field group, one after the
+    // other, in every shading pass and every Phong term).
+    LightRec lights_k[MAX_LIGHTS];
 };
 
 // Counter block (uint32 words) in device memory, zeroed before every batch.
@@ -66,7 +72,11 @@ enum {
     WORK_WORDS = 2 * WORK_HALF,  // two sets of heads: a primaries-first launch runs two persistent kernels per batch
     PRE_SEG = 4096,     // primaries per block of the classification passes between them
     POOL_RUN = 128,     // bounce-child path nodes a wave reserves with one atomic
-    SHADE_LIST = 192    // hits a wave can have waiting for its shading pass (behind its work stack)
+    SHADE_LIST = 192,   // words behind a wave's work stack (round 2: its shading list; now in LDS -- the diagnostics keep two entries here)
+#ifndef RTX_SHADE_LDS
+#define RTX_SHADE_LDS 128
+#endif
+    SHADE_LDS = RTX_SHADE_LDS  // hits a wave can have waiting for its shading pass (LDS; at most RTX_SHADE_MIN - 1 + 64 ever wait)
 };
 static_assert(CTR_BOUNCE_LO % 2 == 0 && CTR_MAX_STEPS < CTR_UTIL && CTR_UTIL + 44 <= CTR_WORDS, "64-bit counters must be 8-byte aligned");
 

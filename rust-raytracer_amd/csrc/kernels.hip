@@ -72,6 +72,31 @@ constexpr float ILL_INV = RTX_ILL_INV;  // |1/d_i| beyond which axis i is left o
 #define RTX_TRACE_WAVES 5  // waves per SIMD the trace kernels are register-allocated for (<= 96 VGPRs)
 #endif
 
+// Experiment switches of round 3, second half (each measured on its own, tests/run_gpu_r03_trim.sh)
+#ifndef RTX_LIGHTS_K
+#define RTX_LIGHTS_K 1      // loops over the lights read them from the kernel arguments (scalar loads)
+#endif
+#ifndef RTX_FAST_THR
+#define RTX_FAST_THR 1      // the pass threshold (a scheduling heuristic) with v_rcp / v_sqrt instead of IEEE division and square root
+#endif
+#ifndef RTX_ONE_SQRT
+#define RTX_ONE_SQRT 1      // a shadow query's direction and distance from ONE square root
+#endif
+#ifndef RTX_ROOM_MUL
+#define RTX_ROOM_MUL 1      // admission of new primaries without the integer division in the common case
+#endif
+#ifndef RTX_SHADE_IN_LDS
+#define RTX_SHADE_IN_LDS 1  // the hits that wait for a shading pass are listed in LDS (else behind the wave's work stack)
+#endif
+#ifndef RTX_FAST_INV
+#define RTX_FAST_INV 0      // 1/d for the slab tests from v_rcp + one Newton step instead of the IEEE division
+#endif
+#if RTX_LIGHTS_K
+#define RTX_LIGHT(sc, l) (sc).lights_k[l]
+#else
+#define RTX_LIGHT(sc, l) (sc).lights[l]
+#endif
+
 // ---------------------------------------------------------------- cgmath-order arithmetic
 struct F3 {
     float x, y, z;
@@ -186,7 +211,17 @@ template <bool XFC>
 __device__ __forceinline__ void init_ray(RayCtx &r, const DeviceScene &sc, F3 o, F3 d) {
     r.o = o;
     r.d = d;
+#if RTX_FAST_INV
+    {   // 1/d within 1 ulp: v_rcp_f32 (1 ulp) + one Newton step; the slab tests' error band allows for 2 u on it
+        float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+        ix = __builtin_fmaf(ix, __builtin_fmaf(-d.x, ix, 1.0f), ix);
+        iy = __builtin_fmaf(iy, __builtin_fmaf(-d.y, iy, 1.0f), iy);
+        iz = __builtin_fmaf(iz, __builtin_fmaf(-d.z, iz, 1.0f), iz);
+        r.inv = f3(ix, iy, iz);
+    }
+#else
     r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
     const bool fin = isfinite(r.inv.x) && isfinite(r.inv.y) && isfinite(r.inv.z) && isfinite(o.x) && isfinite(o.y) &&
                      isfinite(o.z);
     const float big = sc.coord_scale + fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
@@ -433,10 +468,11 @@ struct Stack {
     GlobalStackPtr spill;   // this thread's column of [MAX_TREE_DEPTH - LDS_STACK][threads]
     uint32_t spill_stride;
     int sp;
+    int nlds;               // entries kept in LDS: a constant of the kernel variant (path_body), folded after inlining
     __device__ __forceinline__ void push(uint32_t ref, float t) {
         unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(t) << 32);
-        if (sp < LDS_STACK) lds[sp * TBLOCK] = e;
-        else spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
+        if (sp < nlds) lds[sp * TBLOCK] = e;
+        else spill[(size_t)(sp - nlds) * spill_stride] = e;
         sp++;
     }
     // Pops the next entry whose box can still matter; TRAV_DONE when the stack is empty.
@@ -444,8 +480,8 @@ struct Stack {
         while (sp > 0) {
             sp--;
             unsigned long long e;
-            if (sp < LDS_STACK) e = lds[sp * TBLOCK];
-            else e = spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            if (sp < nlds) e = lds[sp * TBLOCK];
+            else e = spill[(size_t)(sp - nlds) * spill_stride];
             if (!(__uint_as_float((uint32_t)(e >> 32)) > limit_plus)) return (uint32_t)e;
         }
         return TRAV_DONE;
@@ -1084,7 +1120,15 @@ __device__ __forceinline__ void ray_hist(uint32_t *ctr, uint32_t cls, uint32_t r
 #endif
 template <bool COUNT, bool REF, bool OVH, bool SHADE, bool BANK, bool PRE, bool XFC>
 __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr, uint32_t max_levels) {
-    __shared__ unsigned long long lds_stack[LDS_STACK * TBLOCK];
+    // The block's 30,464 bytes of LDS (five blocks per CU), two ways.  Scenes of long rays (BANK: >= 8 M primitives,
+    // trees 30 levels deep): LDS_STACK_DEEP traversal-stack entries per lane, the hits that wait for a shading pass
+    // listed in global memory behind the wave's work stack.  All others: LDS_STACK entries per lane and that list in
+    // LDS -- one round trip less per shading pass (headline -0.7 %, Suzanne -1 %; the 20 M soup +3 % with the
+    // shorter stack, hence the split).
+    constexpr bool SHADE_IN_LDS = RTX_SHADE_IN_LDS && !BANK;
+    constexpr int NLDS = SHADE_IN_LDS ? LDS_STACK : LDS_STACK_DEEP;
+    __shared__ unsigned long long lds_stack[NLDS * TBLOCK];
+    __shared__ unsigned long long lds_shade[SHADE_IN_LDS ? (TBLOCK / 64) * SHADE_LDS : 1];
     __shared__ v4f lds_top_store[TOP_NODES ? TOP_NODES * 7 : 1];
     const LdsNodePtr lds_top = (LdsNodePtr)lds_top_store;
     if (TOP_NODES != 0u && !REF) {
@@ -1103,6 +1147,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     st.spill = (GlobalStackPtr)(reinterpret_cast<unsigned long long *>(fr.spill) + gtid);
     st.spill_stride = nthreads;
     st.sp = 0;
+    st.nlds = NLDS;
     Trav s;
     s.cur = s.bank = TRAV_DONE;
     s.nodes = s.prims = 0;
@@ -1112,13 +1157,15 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     uint32_t node = NO_PRIM, tag = 0;
     // the wave's work stack and its run of pool nodes (wave-uniform)
     uint2 *const wk = fr.wstack + (size_t)(gtid / 64u) * (fr.wstack_cap + (uint32_t)SHADE_LIST);
-    uint2 *const wsh = wk + fr.wstack_cap;              // hits waiting for the shading pass: (node, level)
     const uint32_t wk_cap = fr.wstack_cap;
+    // hits that wait for the shading pass: (path node, hit primitive | bounce level << 28)
+    const LdsStackPtr wsh_lds = (LdsStackPtr)(lds_shade + (SHADE_IN_LDS ? (threadIdx.x / 64u) * (uint32_t)SHADE_LDS : 0u));
+    uint2 *const wsh_glb = wk + fr.wstack_cap;
     uint32_t top = 0, shn = 0, run_next = 0, run_end = 0;
     uint32_t n_shadow = 0, n_bounce = 0;
     // entries that one closest-hit query can push when it ends (admission of new primaries)
     uint32_t per_hit = sc.max_bounce;
-    for (uint32_t l = 0; l < sc.n_lights; l++) per_hit += sc.lights[l].type != LIGHT_AMBIENT ? 1u : 0u;
+    for (uint32_t l = 0; l < sc.n_lights; l++) per_hit += RTX_LIGHT(sc, l).type != LIGHT_AMBIENT ? 1u : 0u;
     uint32_t vis_cn = 0, vis_cp = 0, vis_sn = 0, vis_sp = 0, max_steps = 0;  // COUNT
     Util util;
 #ifdef RTX_WAVE_TIMES
@@ -1182,10 +1229,18 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         // k = sqrt(a*a + 128 a) - a.  Long rays (a soup of triangles) want a pass every few lanes,
         // short ones (most primaries miss the model) only once most of the wave waits.
         if (steps_run != 0u) {
+#if RTX_FAST_THR
+            // (a heuristic: the approximate reciprocal and square root, 2 instructions instead of 30)
+            const float r = (float)nfin * __builtin_amdgcn_rcpf((float)steps_run);
+            end_rate = end_rate < 0.0f ? r : 0.75f * end_rate + 0.25f * r;
+            const float a = (float)RTX_EVENT_STEPS * end_rate;
+            const float k = __builtin_amdgcn_sqrtf(a * a + 128.0f * a) - a;
+#else
             const float r = (float)nfin / (float)steps_run;
             end_rate = end_rate < 0.0f ? r : 0.75f * end_rate + 0.25f * r;
             const float a = (float)RTX_EVENT_STEPS * end_rate;
             const float k = sqrtf(a * a + 128.0f * a) - a;
+#endif
             refill_min = k < (float)RTX_REFILL_LO ? (uint32_t)RTX_REFILL_LO : (k > (float)RTX_REFILL_HI ? (uint32_t)RTX_REFILL_HI : (uint32_t)k);
             steps_run = 0;
         }
@@ -1248,7 +1303,11 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 // hits wait in the wave's shading list until enough of them make a full-width pass
                 const bool hitc = finc && s.any;
                 const unsigned long long hm = __ballot(hitc);
-                if (hitc) wsh[shn + rank_below(hm)] = make_uint2(node, tag >> WK_LEVEL_SHIFT);
+                if (hitc) {
+                    const uint2 e = make_uint2(node, s.prim | ((tag >> WK_LEVEL_SHIFT) << 28));
+                    if constexpr (SHADE_IN_LDS) wsh_lds[shn + rank_below(hm)] = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+                    else wsh_glb[shn + rank_below(hm)] = e;
+                }
                 shn += (uint32_t)__popcll(hm);
             }
             if (fin) tag &= ~WK_BUSY;
@@ -1257,7 +1316,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
         // ---- shading pass over the listed hits (world.rs:120-125, material.rs:185-203): which lights
         // want a shadow query, the bounce children; run by the idle lanes once SHADE_MIN hits wait
         if constexpr (SHADE) {
-            if (shn >= (uint32_t)RTX_SHADE_MIN || shn > (uint32_t)SHADE_LIST - 64u || (shn != 0u && wq.exhausted && top < nidle)) {
+            if (shn >= (uint32_t)RTX_SHADE_MIN || shn > (uint32_t)SHADE_LDS - 64u || (shn != 0u && wq.exhausted && top < nidle)) {
                 const uint32_t rank = rank_below(idlem);
                 const uint32_t n_sh = nidle < shn ? nidle : shn;
 #ifdef RTX_UTIL_STATS
@@ -1268,18 +1327,29 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 uint32_t hnode = 0, level = 0, hprim = 0, lit0 = 0, want = 0, nb = 0;
                 F3 p = f3(0.f, 0.f, 0.f), d = p;
                 if (mine) {
-                    const uint2 e = wsh[shn - n_sh + rank];
+                    uint2 e;
+                    if constexpr (SHADE_IN_LDS) {
+                        const unsigned long long w = wsh_lds[shn - n_sh + rank];
+                        e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+                    } else {
+                        e = wsh_glb[shn - n_sh + rank];
+                    }
                     hnode = e.x;
-                    level = e.y;
+                    level = e.y >> 28;
+                    hprim = e.y & 0x0FFFFFFFu;
                     const float4 o4 = fr.ray_o[hnode], d4 = fr.ray_d[hnode];
+                    // Does the hit's material spawn bounce rays?  The primitive's record is asked together with the
+                    // ray's (the list carries the primitive), the material's only for ids in the range that has such
+                    // materials at all; a scene without them (sc.max_bounce == 0) asks nothing.
+                    uint32_t mid = 0xFFFFFFFFu;
+                    if (sc.max_bounce != 0u && level + 1u < max_levels) mid = sc.prims[hprim].meta >> 16;
                     d = f3(d4.x, d4.y, d4.z);
                     p = f3(o4.x, o4.y, o4.z) + o4.w * d;  // world.rs:120
-                    hprim = __float_as_uint(d4.w);
-                    if (level + 1u < max_levels) nb = sc.mats[sc.prims[hprim].meta >> 16].n_bounce;
+                    if (mid >= sc.bounce_mat_lo && mid <= sc.bounce_mat_hi) nb = sc.mats[mid].n_bounce;
                 }
                 shn -= n_sh;
                 for (uint32_t l = 0; l < sc.n_lights; l++) {
-                    const LightRec &L = sc.lights[l];
+                    const LightRec &L = RTX_LIGHT(sc, l);
                     if (L.type == LIGHT_AMBIENT) lit0 |= 1u << l;
                     else if (L.type != LIGHT_CONE || !outside_cone(L, p)) want |= 1u << l;
                 }
@@ -1298,7 +1368,7 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                     }
                     if (wl)
                         wk[top + rank_below(m)] =
-                            make_uint2(hnode, l | (sc.lights[l].type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
+                            make_uint2(hnode, l | (RTX_LIGHT(sc, l).type == LIGHT_DIRECTIONAL ? WK_DIR : 0u) | WK_SHADOW |
                                                   (level << WK_LEVEL_SHIFT));
                     top += cnt;
                     n_shadow += cnt;
@@ -1369,8 +1439,16 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
                 if (SHADE) {
                     const uint32_t inflight = (uint32_t)__popcll(__ballot((tag & (WK_BUSY | WK_SHADOW)) == WK_BUSY));
                     const uint32_t used = top + (inflight + shn) * per_hit, half = wk_cap / 2u;
+#if RTX_ROOM_MUL
+                    // (room for all of them, nearly always: one multiplication instead of the division)
+                    if (used + n_new * per_hit > half) {
+                        const uint32_t room = used < half ? (half - used) / (per_hit ? per_hit : 1u) : 0u;
+                        n_new = n_new < room ? n_new : room;
+                    }
+#else
                     const uint32_t room = used < half ? (half - used) / (per_hit ? per_hit : 1u) : 0u;
                     n_new = n_new < room ? n_new : room;
+#endif
                 }
                 const bool wants = idle && rank >= n_pop && rank < n_pop + n_new;
                 const unsigned long long wmask = __ballot(wants);
@@ -1397,21 +1475,37 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
             // ---- begin the new rays
             if (got) {
                 const float4 o4 = fr.ray_o[node], d4 = fr.ray_d[node];
+                // (a shadow query's light is asked for before the ray's record is looked at: one round trip, not two)
+                F3 lpos = f3(0.f, 0.f, 0.f), ln1 = lpos, ln2 = lpos;
+                if (tag & WK_SHADOW) {
+                    const LightRec &L = sc.lights[tag & WK_LIGHT];
+                    lpos = f3(L.pos[0], L.pos[1], L.pos[2]);
+                    ln1 = f3(L.ndir1[0], L.ndir1[1], L.ndir1[2]);
+                    ln2 = f3(L.ndir2[0], L.ndir2[1], L.ndir2[2]);
+                }
                 F3 ro = f3(o4.x, o4.y, o4.z), rd = f3(d4.x, d4.y, d4.z);
                 float dist = INFINITY;  // closest hit: nothing found yet; directional light: any hit at all blocks
                 if (tag & WK_SHADOW) {
                     const F3 p = ro + o4.w * rd;  // world.rs:120
-                    const LightRec &L = sc.lights[tag & WK_LIGHT];
                     if (tag & WK_DIR) {
                         // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110)
-                        rd = normalize(-f3(L.dir[0], L.dir[1], L.dir[2]));
-                        ro = p + 1e-4f * rd;
-                        rd = normalize(rd);
+                        // Ray::new(point, -direction).offset(1e-4) (light.rs:109-110): both normalisations are the
+                        // flattener's (LightRec::ndir1/2)
+                        ro = p + 1e-4f * ln1;
+                        rd = ln2;
                     } else {
                         // Light::in_shadow (light.rs:81-97)
-                        ro = f3(L.pos[0], L.pos[1], L.pos[2]);
+                        ro = lpos;
+#if RTX_ONE_SQRT
+                        // normalize(p - ro) and magnitude(ro - p) (light.rs:82-84) take the square root of the same
+                        // number: the components of ro - p are those of p - ro negated, exactly, and their squares equal
+                        const F3 v = p - ro;
+                        dist = magnitude(v);
+                        rd = v * (1.0f / dist);
+#else
                         rd = normalize(p - ro);
                         dist = magnitude(ro - p);
+#endif
                     }
                 }
                 if (PRE && tag == WK_BUSY) {
@@ -1450,8 +1544,9 @@ __device__ __forceinline__ void path_body(const DeviceScene &sc, const Frame &fr
     }
 #ifdef RTX_WAVE_TIMES
     if (SHADE && lane == 0) {
-        wsh[SHADE_LIST - 2] = make_uint2(wt_begin, wt_dry);
-        wsh[SHADE_LIST - 1] = make_uint2((uint32_t)wall_clock64(), 0x57415645u);
+        uint2 *const wt = wk + fr.wstack_cap;  // (the words behind the wave's work stack)
+        wt[SHADE_LIST - 2] = make_uint2(wt_begin, wt_dry);
+        wt[SHADE_LIST - 1] = make_uint2((uint32_t)wall_clock64(), 0x57415645u);
     }
 #endif
     // what is left of the wave's last run of pool nodes
@@ -1724,7 +1819,7 @@ __device__ __forceinline__ void resolve_node(const DeviceScene &sc, const Frame 
                     F3 sum = f3(0.f, 0.f, 0.f);
                     for (uint32_t l = 0; l < sc.n_lights; l++) {
                         if (!(lk.x & (1u << l))) continue;
-                        const LightRec &L = sc.lights[l];
+                        const LightRec &L = RTX_LIGHT(sc, l);
                         F3 lcol = f3(L.color[0], L.color[1], L.color[2]);
                         F3 lc;
                         if (L.type == LIGHT_AMBIENT) lc = lcol;

@@ -828,6 +828,7 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     if ((rc = upload(c, fs.prim_obj, &ds.prim_obj, c->scene_allocs))) return rc;
     ds.n_prims = d->n_objects;
     ds.n_lights = (uint32_t)fs.lights.size();
+    for (size_t l = 0; l < (size_t)MAX_LIGHTS; l++) ds.lights_k[l] = l < fs.lights.size() ? fs.lights[l] : LightRec{};
     ds.n_wnodes = (uint32_t)fs.wnodes.size();
     ds.root_ref = fs.root_ref;
     ds.wroot_ref = fs.wide_root_ref;
@@ -852,6 +853,8 @@ int rtx_upload_scene(rtx_ctx *c, const rtx_scene_desc *d) {
     c->preorder_sizes = std::move(fs.preorder_sizes);
     c->max_bounce = fs.max_bounce;
     ds.max_bounce = fs.max_bounce;
+    ds.bounce_mat_lo = fs.bounce_mat_lo;
+    ds.bounce_mat_hi = fs.bounce_mat_hi;
     c->per_hit = fs.max_bounce;
     for (const auto &l : fs.lights) c->per_hit += l.type != LIGHT_AMBIENT ? 1u : 0u;
     c->info.n_objects = d->n_objects;
