@@ -352,23 +352,29 @@ def main():
                 "nodes_per_ray": round(nodes / max(rays, 1), 3), "prims_per_ray": round(prims / max(rays, 1), 3)}
 
     # The memory side (fabric reads behind L2 against the level the scene lives in) and, when the PMC summary is valid, the
-    # VALU side: lane-instructions = VALU instructions x the lanes that executed them, against the chip's f32 vector rate
-    # (MI355X_MICROARCH.md: 157.3 TFLOP/s f32 = 78.6 T lane-FMA/s, a SIMD retiring a wave64 instruction every 2 cycles).
+    # VALU side: lane-instructions = VALU instructions x the lanes that executed them, against the rate at which this chip
+    # retires unpacked f32 vector instructions, MEASURED (tools/valu_ubench.hip, profiles/r03_valu_ubench.txt): with 5-8 waves
+    # per SIMD a SIMD takes 3.9-4.4 cycles per wave64 v_fma_f32 / v_min_f32 / v_max3_f32 / v_cndmask_b32 -- 16 lanes per
+    # cycle, 40 T lane-instr/s over 1,024 SIMDs at the clock it held -- 2.4-2.8 cycles per v_mul_f32 / v_sub_f32 (two waves
+    # issue together) and 4.3-4.6 per v_pk_*_f32 (two operations per lane: the 157.3 TFLOP/s of the data sheet, 78.6 T
+    # lane-FMA/s, is v_pk_fma_f32).  The path kernel is comparisons, minima, maxima, selects and divisions: the 4-cycle
+    # class is its ceiling; packing its 48 slab subtractions / multiplications per node was measured (+1.6 %).
     memory = {"achieved": round(achieved, 2) if achieved is not None else None, "peak": peak, "unit": "GB/s",
               "frac": round(achieved / peak, 5) if achieved is not None else None,
               "peak_is": ("random 128-byte gathers from L2 + Infinity Cache (scene %.0f MB <= 256 MB)" % (info.device_bytes / 2**20)) if in_mall
                          else "HBM3E (scene %.0f MB > Infinity Cache)" % (info.device_bytes / 2**20),
               "frac_basis": basis}
-    VALU_PEAK_T = 78.6
+    VALU_PEAK_T = 40.2          # measured: v_fma_f32, 8 waves per SIMD, 1.632 ns per wave-instruction per SIMD
+    VALU_PEAK_PACKED_T = 78.6   # data sheet: 157.3 TFLOP/s of packed f32 FMA
     if valu:
         li = valu["insts_per_launch"] * 64.0 * valu["active_lane_fraction"]
         rate = li / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         valu = dict(valu, lane_instr_per_ray=round(li / max(t_rays / max(launches_per_step, 1), 1), 1),
-                    lane_instr_rate_T_per_s=round(rate, 2), lane_instr_peak_T_per_s=VALU_PEAK_T,
-                    note="issue_cycles_over_kernel_cycles prices a wave64 VALU instruction at the 4 cycles it holds its wave's issue slot (a SIMD "
-                         "interleaves two such streams at most): 0.9+ means the issue slots are taken, at active_lane_fraction of the lanes.  "
-                         "Measured in round 3: 14 % fewer VALU instructions bought 5 % of the kernel's time and the waves wait 45 % of "
-                         "their life for loads (SQ_WAIT_ANY / SQ_WAVE_CYCLES): instruction issue AND load latency at 5 waves per SIMD bind together")
+                    lane_instr_rate_T_per_s=round(rate, 2), lane_instr_peak_T_per_s=VALU_PEAK_T, lane_instr_peak_packed_T_per_s=VALU_PEAK_PACKED_T,
+                    note="issue_cycles_over_kernel_cycles prices a wave64 VALU instruction at 4 cycles of its SIMD -- what tools/valu_ubench.hip "
+                         "measures for v_fma / v_min / v_max3 / v_cndmask with 5-8 waves per SIMD (profiles/r03_valu_ubench.txt; subtractions and "
+                         "multiplications retire in 2.4-2.8): 0.9+ means the SIMDs' vector issue is taken, at active_lane_fraction of the lanes; "
+                         "lane_instr_peak_T_per_s is that measured unpacked rate, lane_instr_peak_packed_T_per_s the data sheet's packed-FMA rate")
     if bound == "valu":
         head = {"achieved": valu["lane_instr_rate_T_per_s"], "peak": VALU_PEAK_T, "unit": "T lane-instr/s",
                 "frac": round(valu["lane_instr_rate_T_per_s"] / VALU_PEAK_T, 5)}
