@@ -20,6 +20,9 @@ if [ -f $G/r03/partition_probe.txt ]; then
   { echo "# tools/partition_probe.py 1 2 4 8 16 -- rank 0 share of the headline frame on one MI355X, round-3 kernels; alternating slots = two render slots, then three and four in rotation"; cat $G/r03/partition_probe.txt; } > $P/r03_partition_probe.txt
 fi
 cpif $G/r03/bench.json $P/r03_bench.json
+if [ -f $G/r03/valu_ubench.txt ]; then
+  { echo "# tools/valu_ubench.hip on one MI355X: time per wave64 instruction per SIMD with 1 / 5 / 8 waves per SIMD (a block of 256 = one wave per SIMD; independent instructions, finite data); 'cycles' at an assumed 2.4 / 2.1 GHz -- the ns are the measurement.  The cswap rows execute 10 instructions where the others execute 16: their per-instruction figures are x 1.6"; cat $G/r03/valu_ubench.txt; } > $P/r03_valu_ubench.txt
+fi
 cpif $G/r03/gpu_tests.log $P/r03_gpu_tests.txt
 if [ -f $G/r03/timeline_full.txt ] && [ -f $G/r03/timeline_eighth.txt ]; then
   { echo "# tests/run_gpu_timeline.sh 1 / 8: kernels of one warm frame (ms: start, end, duration), whole frame then rank 0's 1/8 share"; cat $G/r03/timeline_full.txt; echo; cat $G/r03/timeline_eighth.txt; } > $P/r03_frame_timeline.txt

@@ -128,7 +128,7 @@ void run(const char *name, int blocks_per_cu, float *d) {
 int main() {
     float *d;
     hipMalloc(&d, 4);
-    for (int w : {1, 5}) {
+    for (int w : {1, 5, 8}) {
         run<0>("v_fma_f32", w, d);
         run<1>("v_mul_f32", w, d);
         run<4>("v_min_f32", w, d);
