@@ -11,6 +11,7 @@
 //! names it fills against include/rtx.h.
 use cgmath::Matrix4;
 use rtx_sys::*;
+use std::collections::HashMap;
 use std::sync::Arc;
 
 use super::camera::Camera;
@@ -70,9 +71,12 @@ impl FlatScene {
         s.width = camera.width;
         s.height = camera.height;
         // a mesh of a million triangles carries a million copies of the same two matrices and the same
-        // material (object.rs:80-88): consecutive objects are compared with their predecessor only
+        // material (object.rs:80-88): an object is compared with its predecessor first (a mesh is one run), and a
+        // material that differs from it is looked up among all earlier ones by its value (the ABI has 16-bit
+        // material ids: 65,536 DISTINCT materials per scene, however many objects carry each)
         let mut last_xf: Option<([f32; 16], [f32; 16])> = None;
-        let mut last_mat: Option<*const Material> = None;
+        let mut last_mat: Option<(*const Material, i32)> = None;
+        let mut seen: HashMap<Vec<u32>, i32> = HashMap::new();
         for o in objects {
             let (ty, v): (i32, [f32; 12]) = match &o.object_type {
                 ObjectType::Sphere(c, r) => (RTX_OBJ_SPHERE, [c.x, c.y, c.z, *r, 0., 0., 0., 0., 0., 0., 0., 0.]),
@@ -92,14 +96,27 @@ impl FlatScene {
                 last_xf = Some(xf);
             }
             s.obj_xform.push((s.xforms.len() / 32 - 1) as i32);
-            // Material is Clone-d per polygon by new_mesh: value comparison would walk the tree, so only a
-            // run of objects that literally share one texture Arc and one material shape is folded
-            let same_mat = last_mat.map_or(false, |p| unsafe { same_material(&*p, &o.material) });
-            if !same_mat {
-                s.add_material(&o.material);
-                last_mat = Some(&o.material as *const Material);
-            }
-            s.obj_material.push((s.mat_root.len() - 1) as i32);
+            // Material is Clone-d per polygon by new_mesh: the predecessor test folds a run of objects that share one
+            // texture Arc and one material shape without building a key; anything else goes through the table
+            let same_mat = last_mat.map_or(false, |(p, _)| unsafe { same_material(&*p, &o.material) });
+            let id = if same_mat {
+                last_mat.unwrap().1
+            } else {
+                let key = material_key(&o.material);
+                let found = seen.get(&key).map(|v| *v);
+                let id = match found {
+                    Some(id) => id,
+                    None => {
+                        s.add_material(&o.material);
+                        let id = (s.mat_root.len() - 1) as i32;
+                        seen.insert(key, id);
+                        id
+                    }
+                };
+                last_mat = Some((&o.material as *const Material, id));
+                id
+            };
+            s.obj_material.push(id);
         }
         for l in lights {
             let (ty, pos, dir, ang) = match &l.light_type {
@@ -234,6 +251,52 @@ unsafe fn same_material(a: &Material, b: &Material) -> bool {
         _ => false,
     };
     tex && same_type(&a.material_type, &b.material_type)
+}
+
+/// The value of a material as a key: texture identity (the Arc's address / the flat colour's bits) followed by the
+/// MaterialType tree in pre-order, every f32 by its bits.  Equal keys <=> same_material.
+fn material_key(m: &Material) -> Vec<u32> {
+    let mut k: Vec<u32> = Vec::new();
+    match &m.texture_type {
+        TextureType::None => k.push(0),
+        TextureType::Flat(c) => {
+            k.push(1);
+            k.extend(rgb(*c).iter().map(|x| x.to_bits()));
+        }
+        TextureType::Texture(t) => {
+            let a = Arc::as_ptr(t) as usize as u64;
+            k.push(2);
+            k.push(a as u32);
+            k.push((a >> 32) as u32);
+        }
+    }
+    type_key(&m.material_type, &mut k);
+    k
+}
+
+fn type_key(t: &MaterialType, k: &mut Vec<u32>) {
+    match t {
+        MaterialType::None => k.push(10),
+        MaterialType::Reflective => k.push(11),
+        MaterialType::Refractive(x) => {
+            k.push(12);
+            k.push(x.to_bits());
+        }
+        MaterialType::Phong { diffuse, specular, shininess } => {
+            k.push(13);
+            k.push(diffuse.to_bits());
+            k.push(specular.to_bits());
+            k.push(shininess.to_bits());
+        }
+        MaterialType::Composition(v) => {
+            k.push(14);
+            k.push(v.len() as u32);
+            for (m, c) in v.iter() {
+                k.push(c.to_bits());
+                type_key(m, k);
+            }
+        }
+    }
 }
 
 fn same_type(a: &MaterialType, b: &MaterialType) -> bool {
