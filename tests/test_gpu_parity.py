@@ -686,3 +686,87 @@ def test_adversarial_lights_scene_matches_oracle(rt, orc, gpu):
         ok, frac, worst = _image_close(img_g, img_o)
         assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
         assert abs(int(st_g.shadow_rays) - int(st_o.shadow_rays)) <= max(4, st_o.shadow_rays // 10000)
+
+
+def _lights_scene(path, n_lights):
+    """A glass / mirror / Phong scene under `n_lights` lights of all four kinds in turn (ambient, point, directional,
+    cone), the last one directional: the light mask of a path node has 16 bits, the lights sit in the kernel
+    arguments (DeviceScene::lights_k[16]) and in a table for per-lane look-ups."""
+    lines = ["shader s phong 0.7 0.3 4", "shader r reflective", "shader g refractive 1.3", "shader k mix 0.4 r 0.4 g 0.2 s",
+             "texture t flat 0.8 0.7 0.3", "texture c image media:texture.png", "material m k t", "material f s c",
+             "quad f -5 -1 5   5 -1 5   5 -1 -5   -5 -1 -5", "mesh f media:Suzanne.obj", "sphere m -2.2 0 -0.5 1"]
+    for i in range(n_lights):
+        a = 2.0 * np.pi * i / max(n_lights, 1)
+        x, z = 3.0 * np.cos(a), 3.0 * np.sin(a)
+        c = "%.3f %.3f %.3f" % (0.15 + 0.05 * (i % 3), 0.2, 0.1 + 0.05 * (i % 4))
+        kind = 2 if i == n_lights - 1 else i % 4
+        if kind == 0:
+            lines.append("light ambient 0.02 0.02 0.02")
+        elif kind == 1:
+            lines.append("light point %.4f 2.5 %.4f   %s" % (x, z, c))
+        elif kind == 2:
+            lines.append("light directional %.4f -1 %.4f   %s" % (-0.3 * np.cos(a), -0.3 * np.sin(a), c))
+        else:
+            lines.append("light cone %.4f 3 %.4f   %.4f -3 %.4f   35   %s" % (x, z, -x, -z, c))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def test_sixteen_lights_none_and_too_many(rt, orc, gpu, tmp_path):
+    """The limits of the light table: 16 lights (every bit of a node's light mask, every entry of the copy in the
+    kernel arguments) against the oracle; no light at all; a 17th is refused at upload."""
+    p16 = str(tmp_path / "l16.scene")
+    _lights_scene(p16, 16)
+    s, o = _pair(rt, orc, gpu, "file:" + p16, 72, 0)
+    assert s.desc.contents.n_lights == 16
+    obj_o, t_o = o.trace_primary()
+    obj_g, t_g = gpu.trace_primary()
+    assert np.array_equal(obj_g, obj_o) and np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    for spp in (1, 2):
+        img_o, st_o = o.render(spp=spp, bounces=3, seed=5)
+        img_g, st_g = gpu.render(spp=spp, bounces=3, seed=5)
+        ok, frac, worst = _image_close(img_g, img_o)
+        assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
+        assert st_g.shadow_rays > 4 * st_g.primary_rays // 2   # (twelve lights ask for shadow queries)
+        assert abs(int(st_g.shadow_rays) - int(st_o.shadow_rays)) <= max(4, st_o.shadow_rays // 10000)
+    img_ref, _ = gpu.render(spp=2, bounces=3, seed=5, flags=rt.FLAG_REFERENCE_TRAVERSAL)
+    img_g, _ = gpu.render(spp=2, bounces=3, seed=5)
+    assert np.array_equal(img_g, img_ref)
+    p0 = str(tmp_path / "l0.scene")
+    _lights_scene(p0, 0)
+    s, o = _pair(rt, orc, gpu, "file:" + p0, 48, 0)
+    img_o, st_o = o.render(spp=1, bounces=3, seed=5)
+    img_g, st_g = gpu.render(spp=1, bounces=3, seed=5)
+    assert st_g.shadow_rays == 0 and st_o.shadow_rays == 0 and _image_close(img_g, img_o)[0]
+    p17 = str(tmp_path / "l17.scene")
+    _lights_scene(p17, 17)
+    with pytest.raises(rt.RtxError) as e:
+        gpu.upload(rt.HostScene("file:" + p17, 48, 0))
+    assert e.value.status == rt.RTX_ERR_CAPACITY
+
+
+def test_bounce_materials_between_plain_ones(rt, orc, gpu, tmp_path):
+    """The shading pass asks for a hit's material record only when its id lies in the range of the materials that
+    spawn bounce rays (DeviceScene::bounce_mat_lo / hi); here plain Phong materials sit below, between and above the
+    mirror and the glass mix, so the range has holes and objects on both sides of it."""
+    lines = ["shader p phong 0.7 0.3 4", "shader q phong 0.5 0.5 16", "shader r reflective", "shader g refractive 1.3",
+             "shader km mix 0.5 r 0.5 p", "shader kg mix 0.6 g 0.4 q",
+             "texture t1 flat 0.8 0.3 0.3", "texture t2 flat 0.3 0.8 0.3", "texture t3 flat 0.3 0.3 0.8", "texture c image media:texture.png",
+             "material a p c", "material b km t1", "material c q t2", "material d kg t3", "material e p t1",
+             "quad a -5 -1 5   5 -1 5   5 -1 -5   -5 -1 -5",
+             "sphere b -2.4 0 -1 1", "sphere c -0.8 -0.3 0.6 0.7", "sphere d 0.9 0 -0.6 1", "sphere e 2.6 -0.4 0.4 0.6",
+             "light point 2 3 0.5   1 1 1", "light cone -1.5 2 0   1 -1 0   50   1 0.4 0.4", "light ambient 0.2 0.2 0.2"]
+    path = str(tmp_path / "holes.scene")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    s, o = _pair(rt, orc, gpu, "file:" + path, 96, 0)
+    obj_o, t_o = o.trace_primary()
+    obj_g, t_g = gpu.trace_primary()
+    assert np.array_equal(obj_g, obj_o) and np.array_equal(t_g.view(np.uint32), t_o.view(np.uint32))
+    for bounces in (1, 4):
+        img_o, st_o = o.render(spp=2, bounces=bounces, seed=7)
+        img_g, st_g = gpu.render(spp=2, bounces=bounces, seed=7)
+        ok, frac, worst = _image_close(img_g, img_o)
+        assert ok, f"only {frac:.5f} of pixels within 1/255 (worst {worst})"
+        assert st_g.bounce_rays == st_o.bounce_rays and (bounces == 1) == (st_g.bounce_rays == 0)
+        assert abs(int(st_g.shadow_rays) - int(st_o.shadow_rays)) <= max(4, st_o.shadow_rays // 10000)
